@@ -1,0 +1,131 @@
+"""ctypes binding of libcellscreen.so (include/cellscreen.h).  Thin by design: argument
+marshalling and error translation only.  No computation happens here and there is no
+fallback: if the library or a GPU is missing, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+CS_MAX_CONV = 16
+CS_MEM_HOST, CS_MEM_DEVICE = 0, 1
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libcellscreen.so")
+
+
+class CellScreenError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libcellscreen status {status}: {message}")
+        self.status = status
+
+
+class CSCaeWeights(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
+                ("channels", C.c_int32 * CS_MAX_CONV),
+                ("kernel", C.c_void_p * CS_MAX_CONV), ("bias", C.c_void_p * CS_MAX_CONV),
+                ("bn_gamma", C.c_void_p * CS_MAX_CONV), ("bn_beta", C.c_void_p * CS_MAX_CONV),
+                ("bn_mean", C.c_void_p * CS_MAX_CONV), ("bn_var", C.c_void_p * CS_MAX_CONV),
+                ("bn_eps", C.c_float)]
+
+
+class CSOcsvmParams(C.Structure):
+    _fields_ = [("n_sv", C.c_int32), ("support_vectors", C.c_void_p), ("dual_coef", C.c_void_p),
+                ("gamma", C.c_double), ("rho", C.c_double)]
+
+
+class CSDetectorParams(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("n_components", C.c_int32),
+                ("scaler_center", C.c_void_p), ("scaler_scale", C.c_void_p),
+                ("pca_components", C.c_void_p), ("pca_mean_proj", C.c_void_p),
+                ("conservative", CSOcsvmParams), ("moderate", CSOcsvmParams)]
+
+
+class CSModelInfo(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
+                ("feature_dim", C.c_int32), ("n_components", C.c_int32),
+                ("n_sv_conservative", C.c_int32), ("n_sv_moderate", C.c_int32),
+                ("shared_encoder", C.c_int32), ("has_detector", C.c_int32), ("device_id", C.c_int32),
+                ("chunk_cells", C.c_int64)]
+
+
+# every exported symbol of include/cellscreen.h: (restype, argtypes)
+_P, _I, _L = C.c_void_p, C.c_int, C.c_int64
+SIGNATURES = {
+    "cs_abi_version": (_I, []),
+    "cs_status_string": (C.c_char_p, [_I]),
+    "cs_last_error": (C.c_char_p, []),
+    "cs_device_count": (_I, []),
+    "cs_model_load": (_I, [C.c_char_p, _I, C.POINTER(_P)]),
+    "cs_model_from_arrays": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSCaeWeights), C.POINTER(CSDetectorParams), _I, C.POINTER(_P)]),
+    "cs_model_free": (None, [_P]),
+    "cs_model_get_info": (_I, [_P, C.POINTER(CSModelInfo)]),
+    "cs_model_set_chunk": (_I, [_P, _L]),
+    "cs_screen": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I]),
+    "cs_reconstruct": (_I, [_P, _P, _L, _I, _P, _P, _P, _I]),
+    "cs_encode": (_I, [_P, _P, _L, _I, _I, _P, _I]),
+    "cs_layer_output": (_I, [_P, _P, _L, _I, _I, _P, _I]),
+    "cs_scaler_pca": (_I, [_P, _P, _L, _I, _P, _I]),
+    "cs_svm_decision": (_I, [_P, _P, _L, _I, _P, _P, _I]),
+    "cs_synth_crops": (_I, [_P, C.c_uint64, _L, _L, C.c_int32, _P]),
+    "cs_profile_enable": (_I, [_P, _I]),
+    "cs_profile_reset": (_I, [_P]),
+    "cs_profile_kernel_count": (_I, []),
+    "cs_profile_kernel_name": (C.c_char_p, [_I]),
+    "cs_profile_get": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libcellscreen.so and bind every symbol of the header.  torch (if importable) is
+    imported first so the process holds ONE HIP runtime: torch bundles libamdhip64.so.7 and
+    the dynamic linker then resolves our NEEDED entry to that already-loaded copy."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not built; run `python cell-image-analysis_amd/build.py` "
+                                "(or __graft_entry__.build()).  There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (plumbing only: shares its HIP runtime)
+    except Exception:
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cs_abi_version() != 1:
+        raise RuntimeError("libcellscreen ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        lib = load_library()
+        msg = lib.cs_last_error().decode(errors="replace") or lib.cs_status_string(status).decode()
+        raise CellScreenError(status, msg)
+
+
+def _ptr(a) -> Optional[int]:
+    """Address of a numpy array (host) or anything exposing data_ptr() (torch tensor)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(f"cannot take the address of {type(a)}")
+
+
+def mem_kind(a) -> int:
+    if a is None or isinstance(a, np.ndarray):
+        return CS_MEM_HOST
+    if hasattr(a, "is_cuda"):
+        return CS_MEM_DEVICE if a.is_cuda else CS_MEM_HOST
+    raise TypeError(f"unsupported buffer type {type(a)}")

@@ -1,0 +1,190 @@
+"""model_dir persistence -- the load side of ProductionMutantScreening.load_trained_models
+(improved_detection.py:23-46) and the save side of the trainer
+(CAE_improved_modeltrain.py:270-275, 299-300, 437-444).
+
+Native format: <model_dir>/cae.bin + detector.bin + manifest.json.  The .bin files are
+"tensor archives" (layout in csrc/tensor_archive.hpp) that libcellscreen reads itself
+(cs_model_load).  The reference's own files can be converted when their libraries are
+importable: sklearn pickles via pickle (sklearn is installed), Keras weights from a
+.npz export (h5py/Keras are not installed here, so .keras itself is not readable).
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+import struct
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import spec
+from .spec import CAEWeights, DetectorParams, OCSVMParams
+
+_MAGIC = b"CSTENS01"
+_DTYPES = {np.dtype("float32"): 0, np.dtype("float64"): 1, np.dtype("int32"): 2, np.dtype("int64"): 3}
+_RDTYPES = {v: k for k, v in _DTYPES.items()}
+
+
+def write_archive(path: str, tensors: Dict[str, np.ndarray]) -> None:
+    with open(path, "wb") as f:
+        f.write(_MAGIC)
+        f.write(struct.pack("<I", len(tensors)))
+        for name, arr in tensors.items():
+            a = np.ascontiguousarray(arr)
+            if a.dtype not in _DTYPES:
+                raise TypeError(f"{name}: unsupported dtype {a.dtype}")
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)))
+            f.write(nb)
+            f.write(struct.pack("<II", _DTYPES[a.dtype], a.ndim))
+            for d in a.shape:
+                f.write(struct.pack("<Q", d))
+            f.write(struct.pack("<Q", a.nbytes))
+            f.write(b"\0" * ((8 - f.tell() % 8) % 8))
+            f.write(a.tobytes())
+            f.write(b"\0" * ((8 - f.tell() % 8) % 8))
+
+
+def read_archive(path: str) -> Dict[str, np.ndarray]:
+    out = {}
+    with open(path, "rb") as f:
+        if f.read(8) != _MAGIC:
+            raise ValueError(f"{path}: bad magic")
+        (count,) = struct.unpack("<I", f.read(4))
+        for _ in range(count):
+            (nl,) = struct.unpack("<I", f.read(4))
+            name = f.read(nl).decode()
+            dt, nd = struct.unpack("<II", f.read(8))
+            dims = struct.unpack("<" + "Q" * nd, f.read(8 * nd)) if nd else ()
+            (nbytes,) = struct.unpack("<Q", f.read(8))
+            f.seek((8 - f.tell() % 8) % 8, 1)
+            data = f.read(nbytes)
+            if len(data) != nbytes:
+                raise ValueError(f"{path}: truncated tensor {name}")
+            f.seek((8 - f.tell() % 8) % 8, 1)
+            out[name] = np.frombuffer(data, dtype=_RDTYPES[dt]).reshape(dims).copy()
+    return out
+
+
+def _cae_tensors(prefix: str, w: CAEWeights) -> Dict[str, np.ndarray]:
+    t = {}
+    for l in range(w.n_conv):
+        t[f"{prefix}.conv{l}.kernel"] = w.kernels[l].astype(np.float32)
+        t[f"{prefix}.conv{l}.bias"] = w.biases[l].astype(np.float32)
+    for l in range(len(w.bn_gamma)):
+        t[f"{prefix}.bn{l}.gamma"] = w.bn_gamma[l].astype(np.float32)
+        t[f"{prefix}.bn{l}.beta"] = w.bn_beta[l].astype(np.float32)
+        t[f"{prefix}.bn{l}.mean"] = w.bn_mean[l].astype(np.float32)
+        t[f"{prefix}.bn{l}.var"] = w.bn_var[l].astype(np.float32)
+    return t
+
+
+def _cae_from_tensors(prefix: str, t: Dict[str, np.ndarray], n_conv: int, n_bn: int, hw, n_enc, eps) -> CAEWeights:
+    return CAEWeights(
+        kernels=[t[f"{prefix}.conv{l}.kernel"] for l in range(n_conv)],
+        biases=[t[f"{prefix}.conv{l}.bias"] for l in range(n_conv)],
+        bn_gamma=[t[f"{prefix}.bn{l}.gamma"] for l in range(n_bn)],
+        bn_beta=[t[f"{prefix}.bn{l}.beta"] for l in range(n_bn)],
+        bn_mean=[t[f"{prefix}.bn{l}.mean"] for l in range(n_bn)],
+        bn_var=[t[f"{prefix}.bn{l}.var"] for l in range(n_bn)],
+        input_hw=tuple(hw), n_enc=n_enc, bn_eps=eps).validate()
+
+
+def save_model_dir(model_dir: str, autoencoder: CAEWeights, encoder: Optional[CAEWeights] = None,
+                   detector: Optional[DetectorParams] = None, extra: Optional[dict] = None) -> None:
+    """Writes the native file set.  `encoder` is the encoder.keras weight set
+    (CAE_improved_modeltrain.py:300); omit it when it equals the autoencoder's encoder half."""
+    os.makedirs(model_dir, exist_ok=True)
+    autoencoder.validate()
+    t = {"meta": np.array([autoencoder.input_hw[0], autoencoder.input_hw[1], autoencoder.n_conv,
+                           autoencoder.n_enc, *autoencoder.channels], dtype=np.int32),
+         "bn_eps": np.array([autoencoder.bn_eps], dtype=np.float32)}
+    t.update(_cae_tensors("ae", autoencoder))
+    if encoder is not None:
+        t.update(_cae_tensors("enc", encoder))
+    write_archive(os.path.join(model_dir, spec.NATIVE_CAE), t)
+    if detector is not None:
+        d = {"scaler.center": detector.scaler_center.astype(np.float32),
+             "scaler.scale": detector.scaler_scale.astype(np.float64),
+             "pca.components": detector.pca_components.astype(np.float32),
+             "pca.mean": detector.pca_mean.astype(np.float32),
+             "pca.mean_proj": detector.pca_mean_proj.astype(np.float32)}
+        for name, p in (("svm_conservative", detector.conservative), ("svm_moderate", detector.moderate)):
+            d[f"{name}.sv"] = np.ascontiguousarray(p.support_vectors, dtype=np.float64)
+            d[f"{name}.dual_coef"] = np.ascontiguousarray(p.dual_coef, dtype=np.float64).ravel()
+            d[f"{name}.gamma"] = np.array([p.gamma], dtype=np.float64)
+            d[f"{name}.rho"] = np.array([p.rho], dtype=np.float64)
+        write_archive(os.path.join(model_dir, spec.NATIVE_DETECTOR), d)
+    manifest = {"format": "cellscreen-model-dir", "version": 1,
+                "input_hw": list(autoencoder.input_hw), "channels": list(autoencoder.channels),
+                "n_enc": autoencoder.n_enc, "separate_encoder": encoder is not None,
+                "has_detector": detector is not None}
+    if detector is not None:
+        manifest.update(n_components=detector.n_components, n_sv_conservative=detector.conservative.n_sv,
+                        n_sv_moderate=detector.moderate.n_sv)
+    if extra:
+        manifest.update(extra)
+    with open(os.path.join(model_dir, spec.NATIVE_MANIFEST), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+def load_model_dir(model_dir: str):
+    """-> (autoencoder, encoder_or_None, detector_or_None) as numpy containers."""
+    t = read_archive(os.path.join(model_dir, spec.NATIVE_CAE))
+    meta = t["meta"]
+    hw, n_conv, n_enc = (int(meta[0]), int(meta[1])), int(meta[2]), int(meta[3])
+    eps = float(t["bn_eps"][0])
+    ae = _cae_from_tensors("ae", t, n_conv, n_conv - 1, hw, n_enc, eps)
+    enc = _cae_from_tensors("enc", t, n_enc, n_enc, hw, n_enc, eps) if "enc.conv0.kernel" in t else None
+    det = None
+    dpath = os.path.join(model_dir, spec.NATIVE_DETECTOR)
+    if os.path.exists(dpath):
+        d = read_archive(dpath)
+        svm = lambda n: OCSVMParams(d[f"{n}.sv"], d[f"{n}.dual_coef"], float(d[f"{n}.gamma"][0]), float(d[f"{n}.rho"][0]))
+        det = DetectorParams(d["scaler.center"], d["scaler.scale"], d["pca.components"], d["pca.mean"],
+                             d["pca.mean_proj"], svm("svm_conservative"), svm("svm_moderate"))
+    return ae, enc, det
+
+
+# ---- conversion from the reference's sklearn objects (CAE_improved_modeltrain.py:437-444) ----
+def ocsvm_params_from_sklearn(det) -> OCSVMParams:
+    """sklearn.svm.OneClassSVM -> arrays.  decision_function = sum_i dual_coef_i k(x, sv_i) +
+    intercept_ (sklearn svm/_base.py), libsvm's rho = -intercept_ = offset_ (_classes.py:1735)."""
+    if det.kernel != "rbf":
+        raise ValueError("only kernel='rbf' is on the reference path (CAE_improved_modeltrain.py:421)")
+    return OCSVMParams(np.ascontiguousarray(det.support_vectors_, dtype=np.float64),
+                       np.ascontiguousarray(det.dual_coef_, dtype=np.float64).ravel(),
+                       float(det._gamma), float(-det.intercept_[0]))
+
+
+def detector_params_from_sklearn(scaler, pca, det_conservative, det_moderate) -> DetectorParams:
+    comps = np.ascontiguousarray(pca.components_)
+    mean = np.asarray(pca.mean_)
+    if pca.whiten:
+        raise ValueError("PCA(whiten=True) is not on the reference path")
+    # the exact expression PCA.transform evaluates on every call (sklearn _base.py:147-155)
+    mean_proj = (mean.reshape(1, -1) @ comps.T).ravel()
+    return DetectorParams(np.asarray(scaler.center_), np.asarray(scaler.scale_, dtype=np.float64),
+                          comps, mean, mean_proj,
+                          ocsvm_params_from_sklearn(det_conservative), ocsvm_params_from_sklearn(det_moderate))
+
+
+def detector_from_reference_pickles(model_dir: str) -> DetectorParams:
+    """Reads scaler.pkl / pca.pkl / detector_*.pkl as improved_detection.py:32-41 does."""
+    def ld(name):
+        with open(os.path.join(model_dir, name), "rb") as f:
+            return pickle.load(f)
+    return detector_params_from_sklearn(ld("scaler.pkl"), ld("pca.pkl"), ld("detector_conservative.pkl"),
+                                        ld("detector_moderate.pkl"))
+
+
+def cae_from_npz(path: str, prefix: str = "") -> CAEWeights:
+    """Keras weights exported as arrays named conv{l}_kernel, conv{l}_bias, bn{l}_gamma, ..."""
+    z = np.load(path)
+    n_conv = sum(1 for k in z.files if k.startswith(prefix + "conv") and k.endswith("_kernel"))
+    n_bn = sum(1 for k in z.files if k.startswith(prefix + "bn") and k.endswith("_gamma"))
+    g = lambda n: np.asarray(z[prefix + n], dtype=np.float32)
+    return CAEWeights([g(f"conv{l}_kernel") for l in range(n_conv)], [g(f"conv{l}_bias") for l in range(n_conv)],
+                      [g(f"bn{l}_gamma") for l in range(n_bn)], [g(f"bn{l}_beta") for l in range(n_bn)],
+                      [g(f"bn{l}_mean") for l in range(n_bn)], [g(f"bn{l}_var") for l in range(n_bn)]).validate()

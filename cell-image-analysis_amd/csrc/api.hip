@@ -1,0 +1,787 @@
+// api.hip -- the C ABI of libcellscreen.so (include/cellscreen.h): model construction,
+// workspace, chunked orchestration of the kernels, measurement hooks.
+// There is deliberately no CPU path here: without a HIP device every compute entry
+// point fails with CS_ERR_NO_DEVICE.
+#include "../../include/cellscreen.h"
+#include "common.hpp"
+#include "tensor_archive.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cs;
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(CS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- the reference graph
+static const int kRefChannels[7] = {32, 64, 32, 32, 64, 32, 1};
+static const int kNConv = 7, kNEnc = 3, kH = 64, kW = 64;
+// stored per-cell size (floats) of each conv's output tensor (after pool / before upsample)
+static const size_t kLayerFloats[7] = {32 * 32 * 32, 16 * 16 * 64, 8 * 8 * 32, 8 * 8 * 32,
+                                       16 * 16 * 64, 32 * 32 * 32, 64 * 64};
+// conv MACs per cell, SURVEY.md Appendix A.1
+static const double kLayerMacs[7] = {1179648, 18874368, 4718592, 589824, 4718592, 18874368, 1179648};
+static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool",
+                                            "conv4_relu_bn",      "conv5_up_relu_bn",   "conv6_up_relu_bn",
+                                            "conv7_up_sigmoid_err", "scaler_pca",       "ocsvm_decision",
+                                            "finalize",           "synth_crops"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return CS_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { p = nullptr; return fail(CS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
+        bytes = need;
+        return CS_OK;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct ConvSet {           // one weight set on device, packed for the kernels
+    DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
+    DevBuf ep[6];          // [3][cout] bias, bn_scale, bn_shift
+    int n = 0;             // number of convs packed (6 for the autoencoder, 3 for encoder.keras)
+};
+
+struct ProfEvent { int kid; hipEvent_t a, b; int64_t cells; };
+
+struct cs_model {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ConvSet ae, enc;
+    bool shared_encoder = true;
+    float w7[9 * 32];
+    float b7 = 0.0f;
+    // detector
+    bool has_det = false;
+    int F = 0, fpad = 0, C = 0, cpad = 0;
+    DevBuf center, scale, comps, mean_proj;
+    struct Svm { DevBuf svT, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
+    // workspace (per chunk)
+    int64_t chunk = 4096;
+    int64_t ws_cells = 0;
+    DevBuf xin, act[6], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> pending;
+    double prof_ms[K_COUNT] = {0};
+    int64_t prof_launches[K_COUNT] = {0};
+    int64_t prof_cells[K_COUNT] = {0};
+    ~cs_model()
+    {
+        for (auto& e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ---------------------------------------------------------------- small helpers
+static int upload(DevBuf& d, const void* src, size_t bytes)
+{
+    int rc = d.ensure(bytes ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+    return CS_OK;
+}
+
+static int check_arch(const cs_cae_weights* w, int expect_convs, const char* what)
+{
+    if (!w) return fail(CS_ERR_INVALID, "%s weights are NULL", what);
+    if (w->height != kH || w->width != kW)
+        return fail(CS_ERR_UNSUPPORTED, "%s: input %dx%d unsupported (this build has kernels for 64x64)", what, w->height, w->width);
+    if (w->n_conv != expect_convs || (expect_convs == kNConv && w->n_enc != kNEnc))
+        return fail(CS_ERR_UNSUPPORTED, "%s: n_conv=%d n_enc=%d unsupported (expected %d/%d)", what, w->n_conv, w->n_enc, expect_convs, kNEnc);
+    for (int l = 0; l < expect_convs; ++l) {
+        if (w->channels[l] != kRefChannels[l])
+            return fail(CS_ERR_UNSUPPORTED, "%s: conv %d has %d filters, this build expects %d", what, l, w->channels[l], kRefChannels[l]);
+        if (!w->kernel[l] || !w->bias[l]) return fail(CS_ERR_INVALID, "%s: conv %d kernel/bias is NULL", what, l);
+        const bool has_bn = l < kNConv - 1;
+        if (has_bn && (!w->bn_gamma[l] || !w->bn_beta[l] || !w->bn_mean[l] || !w->bn_var[l]))
+            return fail(CS_ERR_INVALID, "%s: conv %d BatchNormalization arrays are NULL", what, l);
+    }
+    return CS_OK;
+}
+
+// Pack convs [0, count) of a weight set.  BatchNormalization (inference) is reduced to
+// y = x*s + t with s = gamma / sqrt(var + eps), t = beta - mean*s, all in fp32.
+static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
+{
+    std::vector<float> tmp;
+    for (int l = 0; l < count; ++l) {
+        const int cin = l == 0 ? 1 : kRefChannels[l - 1], cout = kRefChannels[l];
+        const size_t nf = pack_conv_fragments(cin, cout, nullptr, nullptr);
+        tmp.resize(nf);
+        pack_conv_fragments(cin, cout, w->kernel[l], tmp.data());
+        int rc = upload(set.wfrag[l], tmp.data(), nf * sizeof(float));
+        if (rc) return rc;
+        std::vector<float> ep(3 * cout);
+        for (int c = 0; c < cout; ++c) {
+            const float s = w->bn_gamma[l][c] / sqrtf(w->bn_var[l][c] + w->bn_eps);
+            ep[c] = w->bias[l][c];
+            ep[cout + c] = s;
+            ep[2 * cout + c] = w->bn_beta[l][c] - w->bn_mean[l][c] * s;
+        }
+        rc = upload(set.ep[l], ep.data(), ep.size() * sizeof(float));
+        if (rc) return rc;
+    }
+    set.n = count;
+    return CS_OK;
+}
+
+static bool same_encoder(const cs_cae_weights* a, const cs_cae_weights* e)
+{
+    if (a->bn_eps != e->bn_eps) return false;
+    for (int l = 0; l < kNEnc; ++l) {
+        const int cin = l == 0 ? 1 : kRefChannels[l - 1], cout = kRefChannels[l];
+        if (memcmp(a->kernel[l], e->kernel[l], sizeof(float) * 9 * cin * cout)) return false;
+        if (memcmp(a->bias[l], e->bias[l], sizeof(float) * cout)) return false;
+        if (memcmp(a->bn_gamma[l], e->bn_gamma[l], sizeof(float) * cout)) return false;
+        if (memcmp(a->bn_beta[l], e->bn_beta[l], sizeof(float) * cout)) return false;
+        if (memcmp(a->bn_mean[l], e->bn_mean[l], sizeof(float) * cout)) return false;
+        if (memcmp(a->bn_var[l], e->bn_var[l], sizeof(float) * cout)) return false;
+    }
+    return true;
+}
+
+static int pack_svm(cs_model::Svm& s, const cs_ocsvm_params& p, int D, const char* what)
+{
+    if (p.n_sv <= 0 || !p.support_vectors || !p.dual_coef)
+        return fail(CS_ERR_INVALID, "%s detector: n_sv=%d or NULL arrays", what, p.n_sv);
+    s.nsv = p.n_sv;
+    s.nsv_pad = (p.n_sv + 255) / 256 * 256;
+    s.gamma = p.gamma;
+    s.rho = p.rho;
+    std::vector<double> svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0);
+    for (int i = 0; i < p.n_sv; ++i) {
+        coef[i] = p.dual_coef[i];
+        for (int d = 0; d < D; ++d) svT[(size_t)d * s.nsv_pad + i] = p.support_vectors[(size_t)i * D + d];
+    }
+    int rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
+    if (rc) return rc;
+    return upload(s.coef, coef.data(), coef.size() * sizeof(double));
+}
+
+static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
+{
+    if (cells > m->ws_cells) {
+        int rc;
+        if ((rc = m->xin.ensure((size_t)cells * kH * kW * sizeof(float)))) return rc;
+        for (int l = 0; l < 6; ++l)
+            if ((rc = m->act[l].ensure((size_t)cells * kLayerFloats[l] * sizeof(float)))) return rc;
+        if ((rc = m->featE.ensure((size_t)cells * kLayerFloats[2] * sizeof(float)))) return rc;
+        if ((rc = m->pca.ensure((size_t)cells * 256 * sizeof(float)))) return rc;
+        if ((rc = m->errpart.ensure((size_t)cells * 8 * sizeof(float)))) return rc;
+        for (int d = 0; d < 2; ++d) {
+            if ((rc = m->dec[d].ensure((size_t)cells * sizeof(double)))) return rc;
+            if ((rc = m->o_sc[d].ensure((size_t)cells * sizeof(double)))) return rc;
+            if ((rc = m->o_pr[d].ensure((size_t)cells))) return rc;
+        }
+        if ((rc = m->o_mse.ensure((size_t)cells * sizeof(float)))) return rc;
+        if ((rc = m->o_mae.ensure((size_t)cells * sizeof(float)))) return rc;
+        m->ws_cells = cells;
+    }
+    if (need_recon) {
+        int rc = m->recon.ensure((size_t)m->ws_cells * kH * kW * sizeof(float));
+        if (rc) return rc;
+    }
+    return CS_OK;
+}
+
+// ---------------------------------------------------------------- profiled launches
+struct Launch {
+    cs_model* m; int kid; int64_t cells; ProfEvent ev; bool on;
+    Launch(cs_model* m_, int kid_, int64_t cells_) : m(m_), kid(kid_), cells(cells_), on(m_->prof)
+    {
+        if (on) {
+            ev.kid = kid; ev.cells = cells;
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(ev.a, m->stream);
+        }
+    }
+    ~Launch()
+    {
+        if (on) { (void)hipEventRecord(ev.b, m->stream); m->pending.push_back(ev); }
+    }
+};
+
+static int drain_profile(cs_model* m)
+{
+    for (auto& e : m->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            m->prof_ms[e.kid] += ms;
+            m->prof_launches[e.kid] += 1;
+            m->prof_cells[e.kid] += e.cells;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    m->pending.clear();
+    return CS_OK;
+}
+
+#define LAUNCH(kid, cells, call)                                                              \
+    do {                                                                                      \
+        hipError_t le__;                                                                      \
+        { Launch l__(m, kid, cells); le__ = (call); }                                         \
+        if (le__ != hipSuccess)                                                               \
+            return fail(CS_ERR_HIP, "launch %s failed: %s", kKernelNames[kid], hipGetErrorString(le__)); \
+    } while (0)
+
+// Runs convs [first, last] (0-based, inclusive) of weight set `set` on `nc` cells.
+// Layer l reads act[l-1] (or x for l == 0) and writes act[l]; conv 7 (index 6) writes
+// errpart (and recon when asked).
+static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc, int first, int last,
+                     float* recon)
+{
+    for (int l = first; l <= last && l < 6; ++l) {
+        const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        LAUNCH(K_CONV1 + l, nc,
+               launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+    }
+    if (last >= 6)
+        LAUNCH(K_CONV7_ERR, nc,
+               launch_conv7_err(m->act[5].as<float>(), x, m->w7, m->b7, m->errpart.as<float>(), recon, nc, m->stream));
+    return CS_OK;
+}
+
+static int begin_call(cs_model* m)
+{
+    if (!m) return fail(CS_ERR_INVALID, "model handle is NULL");
+    HIPCHK(hipSetDevice(m->device));
+    return CS_OK;
+}
+
+static int end_call(cs_model* m)
+{
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return drain_profile(m);
+}
+
+// Makes chunk [off, off+nc) of a caller buffer available on the device.
+static int stage_in(cs_model* m, const float* base, int kind, int64_t off, int64_t nc, size_t per_cell,
+                    DevBuf& staging, const float** dev)
+{
+    if (kind == CS_MEM_DEVICE) { *dev = base + (size_t)off * per_cell; return CS_OK; }
+    int rc = staging.ensure((size_t)nc * per_cell * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(staging.p, base + (size_t)off * per_cell, (size_t)nc * per_cell * sizeof(float),
+                          hipMemcpyHostToDevice, m->stream));
+    *dev = staging.as<float>();
+    return CS_OK;
+}
+
+template <class T>
+static int stage_out(cs_model* m, T* user, int kind, int64_t off, int64_t count, const T* dev)
+{
+    if (!user || kind == CS_MEM_DEVICE) return CS_OK;  // device outputs are written in place
+    HIPCHK(hipMemcpyAsync(user + off, dev, (size_t)count * sizeof(T), hipMemcpyDeviceToHost, m->stream));
+    return CS_OK;
+}
+
+template <class T>
+static T* out_ptr(T* user, int kind, int64_t off, DevBuf& tmp)
+{
+    if (!user) return nullptr;
+    return kind == CS_MEM_DEVICE ? user + off : tmp.as<T>();
+}
+
+static int check_kind(int k, const char* what)
+{
+    if (k != CS_MEM_HOST && k != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "%s must be CS_MEM_HOST or CS_MEM_DEVICE", what);
+    return CS_OK;
+}
+
+// ================================================================ C ABI
+extern "C" {
+
+int cs_abi_version(void) { return CS_ABI_VERSION; }
+
+const char* cs_status_string(int s)
+{
+    switch (s) {
+        case CS_OK: return "ok";
+        case CS_ERR_INVALID: return "invalid argument";
+        case CS_ERR_IO: return "i/o error";
+        case CS_ERR_FORMAT: return "malformed model file";
+        case CS_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case CS_ERR_HIP: return "HIP runtime error";
+        case CS_ERR_UNSUPPORTED: return "unsupported architecture or size";
+        case CS_ERR_NOMEM: return "out of memory";
+        case CS_ERR_NO_DETECTOR: return "model has no detector parameters";
+        default: return "unknown status";
+    }
+}
+
+const char* cs_last_error(void) { return g_err.c_str(); }
+
+int cs_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights* encoder,
+                         const cs_detector_params* det, int device_id, cs_model** out)
+{
+    if (!out) return fail(CS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = check_arch(autoencoder, kNConv, "autoencoder");
+    if (rc) return rc;
+    if (encoder && (rc = check_arch(encoder, kNEnc, "encoder"))) return rc;
+    const int ndev = cs_device_count();
+    if (ndev <= 0) return fail(CS_ERR_NO_DEVICE, "no HIP device visible; libcellscreen has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return fail(CS_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+
+    cs_model* m = new (std::nothrow) cs_model();
+    if (!m) return fail(CS_ERR_NOMEM, "host allocation failed");
+    m->device = device_id;
+#define FAIL_IF(x) do { int r__ = (x); if (r__) { delete m; return r__; } } while (0)
+    {
+        hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete m; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    }
+    FAIL_IF(pack_set(m->ae, autoencoder, 6));
+    memcpy(m->w7, autoencoder->kernel[6], sizeof m->w7);
+    m->b7 = autoencoder->bias[6][0];
+    m->shared_encoder = !encoder || same_encoder(autoencoder, encoder);
+    if (!m->shared_encoder) FAIL_IF(pack_set(m->enc, encoder, kNEnc));
+
+    if (det) {
+        if (det->n_features != (int)kLayerFloats[2]) {
+            delete m;
+            return fail(CS_ERR_INVALID, "detector n_features=%d but the encoder emits %zu", det->n_features, kLayerFloats[2]);
+        }
+        if (det->n_components <= 0 || det->n_components > 128 || !det->scaler_center || !det->scaler_scale ||
+            !det->pca_components || !det->pca_mean_proj) {
+            delete m;
+            return fail(CS_ERR_INVALID, "detector: n_components=%d (1..128) or NULL arrays", det->n_components);
+        }
+        m->F = det->n_features;
+        m->fpad = (m->F + 511) / 512 * 512;
+        m->C = det->n_components;
+        m->cpad = (m->C + 15) / 16 * 16;
+        FAIL_IF(upload(m->center, det->scaler_center, sizeof(float) * m->F));
+        FAIL_IF(upload(m->scale, det->scaler_scale, sizeof(double) * m->F));
+        std::vector<float> cp((size_t)m->cpad * m->fpad, 0.0f);
+        for (int c = 0; c < m->C; ++c)
+            memcpy(&cp[(size_t)c * m->fpad], det->pca_components + (size_t)c * m->F, sizeof(float) * m->F);
+        FAIL_IF(upload(m->comps, cp.data(), cp.size() * sizeof(float)));
+        FAIL_IF(upload(m->mean_proj, det->pca_mean_proj, sizeof(float) * m->C));
+        FAIL_IF(pack_svm(m->svm[0], det->conservative, m->C, "conservative"));
+        FAIL_IF(pack_svm(m->svm[1], det->moderate, m->C, "moderate"));
+        m->has_det = true;
+    }
+#undef FAIL_IF
+    *out = m;
+    return CS_OK;
+}
+
+// ---- native model_dir ------------------------------------------------------------
+static int fill_weights(const TensorArchive& ar, const std::string& prefix, int n_conv, cs_cae_weights* w,
+                        const std::string& path)
+{
+    for (int l = 0; l < n_conv; ++l) {
+        const int cin = l == 0 ? 1 : w->channels[l - 1], cout = w->channels[l];
+        const std::string cl = prefix + ".conv" + std::to_string(l), bl = prefix + ".bn" + std::to_string(l);
+        const Tensor* k = ar.get(cl + ".kernel");
+        const Tensor* b = ar.get(cl + ".bias");
+        if (!k || !b || !k->f32() || !b->f32() || k->numel() != (size_t)9 * cin * cout || b->numel() != (size_t)cout)
+            return fail(CS_ERR_FORMAT, "%s: missing or mis-shaped %s.kernel/.bias", path.c_str(), cl.c_str());
+        w->kernel[l] = k->f32();
+        w->bias[l] = b->f32();
+        if (l < w->n_conv - 1 || prefix == "enc") {
+            const Tensor* g = ar.get(bl + ".gamma"); const Tensor* be = ar.get(bl + ".beta");
+            const Tensor* mu = ar.get(bl + ".mean"); const Tensor* va = ar.get(bl + ".var");
+            if (!g || !be || !mu || !va || !g->f32() || !be->f32() || !mu->f32() || !va->f32() ||
+                g->numel() != (size_t)cout || be->numel() != (size_t)cout || mu->numel() != (size_t)cout || va->numel() != (size_t)cout)
+                return fail(CS_ERR_FORMAT, "%s: missing or mis-shaped %s.*", path.c_str(), bl.c_str());
+            w->bn_gamma[l] = g->f32(); w->bn_beta[l] = be->f32(); w->bn_mean[l] = mu->f32(); w->bn_var[l] = va->f32();
+        }
+    }
+    return CS_OK;
+}
+
+static int fill_svm(const TensorArchive& ar, const std::string& prefix, int C, cs_ocsvm_params* p, const std::string& path)
+{
+    const Tensor* sv = ar.get(prefix + ".sv"); const Tensor* dc = ar.get(prefix + ".dual_coef");
+    const Tensor* g = ar.get(prefix + ".gamma"); const Tensor* r = ar.get(prefix + ".rho");
+    if (!sv || !dc || !g || !r || !sv->f64() || !dc->f64() || !g->f64() || !r->f64() || sv->dims.size() != 2 ||
+        sv->dims[1] != (uint64_t)C || dc->numel() != sv->dims[0] || g->numel() != 1 || r->numel() != 1)
+        return fail(CS_ERR_FORMAT, "%s: missing or mis-shaped %s.*", path.c_str(), prefix.c_str());
+    p->n_sv = (int32_t)sv->dims[0];
+    p->support_vectors = sv->f64();
+    p->dual_coef = dc->f64();
+    p->gamma = g->f64()[0];
+    p->rho = r->f64()[0];
+    return CS_OK;
+}
+
+int cs_model_load(const char* model_dir, int device_id, cs_model** out)
+{
+    if (!out) return fail(CS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!model_dir) return fail(CS_ERR_INVALID, "model_dir is NULL");
+    const std::string dir(model_dir);
+    TensorArchive cae, det;
+    std::string err = cae.load(dir + "/cae.bin");
+    if (!err.empty()) return fail(err.rfind("cannot open", 0) == 0 ? CS_ERR_IO : CS_ERR_FORMAT, "%s", err.c_str());
+
+    const Tensor* meta = cae.get("meta");
+    const Tensor* eps = cae.get("bn_eps");
+    if (!meta || !meta->i32() || meta->numel() < 5 || !eps || !eps->f32() || eps->numel() != 1)
+        return fail(CS_ERR_FORMAT, "%s/cae.bin: missing meta / bn_eps", model_dir);
+    const int32_t* mi = meta->i32();
+    cs_cae_weights ae;
+    memset(&ae, 0, sizeof ae);
+    ae.height = mi[0]; ae.width = mi[1]; ae.n_conv = mi[2]; ae.n_enc = mi[3];
+    if (ae.n_conv < 2 || ae.n_conv > CS_MAX_CONV || meta->numel() != (size_t)(4 + ae.n_conv))
+        return fail(CS_ERR_FORMAT, "%s/cae.bin: bad meta", model_dir);
+    for (int l = 0; l < ae.n_conv; ++l) ae.channels[l] = mi[4 + l];
+    ae.bn_eps = eps->f32()[0];
+    int rc = fill_weights(cae, "ae", ae.n_conv, &ae, dir + "/cae.bin");
+    if (rc) return rc;
+
+    cs_cae_weights en;
+    const cs_cae_weights* enp = nullptr;
+    if (cae.get("enc.conv0.kernel")) {
+        en = ae;
+        en.n_conv = ae.n_enc;
+        for (int l = 0; l < CS_MAX_CONV; ++l) en.kernel[l] = en.bias[l] = en.bn_gamma[l] = en.bn_beta[l] = en.bn_mean[l] = en.bn_var[l] = nullptr;
+        rc = fill_weights(cae, "enc", en.n_conv, &en, dir + "/cae.bin");
+        if (rc) return rc;
+        enp = &en;
+    }
+
+    cs_detector_params dp;
+    const cs_detector_params* dpp = nullptr;
+    FILE* probe = fopen((dir + "/detector.bin").c_str(), "rb");
+    if (probe) {
+        fclose(probe);
+        err = det.load(dir + "/detector.bin");
+        if (!err.empty()) return fail(CS_ERR_FORMAT, "%s", err.c_str());
+        memset(&dp, 0, sizeof dp);
+        const Tensor* ce = det.get("scaler.center"); const Tensor* sc = det.get("scaler.scale");
+        const Tensor* co = det.get("pca.components"); const Tensor* mp = det.get("pca.mean_proj");
+        if (!ce || !sc || !co || !mp || !ce->f32() || !sc->f64() || !co->f32() || !mp->f32() || co->dims.size() != 2 ||
+            ce->numel() != co->dims[1] || sc->numel() != co->dims[1] || mp->numel() != co->dims[0])
+            return fail(CS_ERR_FORMAT, "%s/detector.bin: missing or mis-shaped scaler/pca tensors", model_dir);
+        dp.n_features = (int32_t)co->dims[1];
+        dp.n_components = (int32_t)co->dims[0];
+        dp.scaler_center = ce->f32(); dp.scaler_scale = sc->f64();
+        dp.pca_components = co->f32(); dp.pca_mean_proj = mp->f32();
+        if ((rc = fill_svm(det, "svm_conservative", dp.n_components, &dp.conservative, dir + "/detector.bin"))) return rc;
+        if ((rc = fill_svm(det, "svm_moderate", dp.n_components, &dp.moderate, dir + "/detector.bin"))) return rc;
+        dpp = &dp;
+    }
+    return cs_model_from_arrays(&ae, enp, dpp, device_id, out);
+}
+
+void cs_model_free(cs_model* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    delete m;
+}
+
+int cs_model_get_info(const cs_model* m, cs_model_info* info)
+{
+    if (!m || !info) return fail(CS_ERR_INVALID, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->height = kH; info->width = kW; info->n_conv = kNConv; info->n_enc = kNEnc;
+    info->feature_dim = (int32_t)kLayerFloats[2];
+    info->n_components = m->C;
+    info->n_sv_conservative = m->svm[0].nsv;
+    info->n_sv_moderate = m->svm[1].nsv;
+    info->shared_encoder = m->shared_encoder ? 1 : 0;
+    info->has_detector = m->has_det ? 1 : 0;
+    info->device_id = m->device;
+    info->chunk_cells = m->chunk;
+    return CS_OK;
+}
+
+int cs_model_set_chunk(cs_model* m, int64_t chunk_cells)
+{
+    if (!m || chunk_cells <= 0 || chunk_cells > (1 << 20)) return fail(CS_ERR_INVALID, "chunk_cells must be in [1, 2^20]");
+    m->chunk = chunk_cells;
+    return CS_OK;
+}
+
+// ---- detector tail on a chunk ------------------------------------------------------
+static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, float* mae, double* sc, double* sm,
+                    int8_t* pc, int8_t* pm, bool with_err)
+{
+    LAUNCH(K_SCALER_PCA, nc,
+           launch_scaler_pca(feat, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
+                             m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+    for (int d = 0; d < 2; ++d)
+        LAUNCH(K_SVM, nc,
+               launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(),
+                            m->svm[d].nsv, m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho,
+                            m->dec[d].as<double>(), nc, m->stream));
+    LAUNCH(K_FINALIZE, nc,
+           launch_finalize(with_err ? m->errpart.as<float>() : nullptr, 4, kH * kW, m->dec[0].as<double>(),
+                           m->dec[1].as<double>(), mse, mae, sc, sm, pc, pm, nc, m->stream));
+    return CS_OK;
+}
+
+int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float* mse, float* mae,
+              double* cons_score, double* mod_score, int8_t* cons_pred, int8_t* mod_pred, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;  // improved_detection.py:119-120
+    if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
+    if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_screen needs detector parameters");
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    if ((rc = ensure_workspace(m, ch, false))) return rc;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* x;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, m->ae, x, nc, 0, 6, nullptr))) return rc;
+        const float* feat = m->act[2].as<float>();
+        if (!m->shared_encoder) {
+            // encoder.keras differs from the autoencoder's encoder half: second encoder pass
+            // (improved_detection.py:130), after the decoder has consumed act[2].
+            if ((rc = run_convs(m, m->enc, x, nc, 0, 2, nullptr))) return rc;
+            feat = m->act[2].as<float>();
+        }
+        float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
+        float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
+        double* d_sc = out_ptr(cons_score, out_kind, off, m->o_sc[0]);
+        double* d_sm = out_ptr(mod_score, out_kind, off, m->o_sc[1]);
+        int8_t* d_pc = out_ptr(cons_pred, out_kind, off, m->o_pr[0]);
+        int8_t* d_pm = out_ptr(mod_pred, out_kind, off, m->o_pr[1]);
+        if ((rc = run_tail(m, feat, nc, d_mse, d_mae, d_sc, d_sm, d_pc, d_pm, true))) return rc;
+        if ((rc = stage_out(m, mse, out_kind, off, nc, d_mse))) return rc;
+        if ((rc = stage_out(m, mae, out_kind, off, nc, d_mae))) return rc;
+        if ((rc = stage_out(m, cons_score, out_kind, off, nc, d_sc))) return rc;
+        if ((rc = stage_out(m, mod_score, out_kind, off, nc, d_sm))) return rc;
+        if ((rc = stage_out(m, cons_pred, out_kind, off, nc, d_pc))) return rc;
+        if ((rc = stage_out(m, mod_pred, out_kind, off, nc, d_pm))) return rc;
+        if (crops_kind == CS_MEM_HOST || out_kind == CS_MEM_HOST) HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, float* recon, float* mse,
+                   float* mae, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
+    if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const bool host_recon = recon && out_kind == CS_MEM_HOST;
+    if ((rc = ensure_workspace(m, ch, host_recon))) return rc;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* x;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
+        float* d_rec = !recon ? nullptr : (out_kind == CS_MEM_DEVICE ? recon + (size_t)off * kH * kW : m->recon.as<float>());
+        if ((rc = run_convs(m, m->ae, x, nc, 0, 6, d_rec))) return rc;
+        float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
+        float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
+        LAUNCH(K_FINALIZE, nc,
+               launch_finalize(m->errpart.as<float>(), 4, kH * kW, nullptr, nullptr, d_mse, d_mae, nullptr, nullptr,
+                               nullptr, nullptr, nc, m->stream));
+        if ((rc = stage_out(m, mse, out_kind, off, nc, d_mse))) return rc;
+        if ((rc = stage_out(m, mae, out_kind, off, nc, d_mae))) return rc;
+        if (host_recon)
+            HIPCHK(hipMemcpyAsync(recon + (size_t)off * kH * kW, d_rec, (size_t)nc * kH * kW * sizeof(float),
+                                  hipMemcpyDeviceToHost, m->stream));
+        if (crops_kind == CS_MEM_HOST || out_kind == CS_MEM_HOST) HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_encode(cs_model* m, const float* crops, int64_t n, int crops_kind, int which, float* features, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!crops || !features) return fail(CS_ERR_INVALID, "crops/features is NULL");
+    if (which != 0 && which != 1) return fail(CS_ERR_INVALID, "which must be 0 (autoencoder) or 1 (encoder.keras)");
+    if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    if ((rc = ensure_workspace(m, ch, false))) return rc;
+    const ConvSet& set = (which == 1 && !m->shared_encoder) ? m->enc : m->ae;
+    const size_t fl = kLayerFloats[2];
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* x;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, set, x, nc, 0, 2, nullptr))) return rc;
+        HIPCHK(hipMemcpyAsync(features + (size_t)off * fl, m->act[2].p, (size_t)nc * fl * sizeof(float),
+                              out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_layer_output(cs_model* m, const float* crops, int64_t n, int crops_kind, int layer, float* out, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!crops || !out) return fail(CS_ERR_INVALID, "crops/out is NULL");
+    if (layer < 0 || layer >= kNConv) return fail(CS_ERR_INVALID, "layer must be in [0,%d)", kNConv);
+    if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    if ((rc = ensure_workspace(m, ch, layer == 6))) return rc;
+    const size_t fl = kLayerFloats[layer];
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* x;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, m->ae, x, nc, 0, layer, layer == 6 ? m->recon.as<float>() : nullptr))) return rc;
+        const void* src = layer == 6 ? m->recon.p : m->act[layer].p;
+        HIPCHK(hipMemcpyAsync(out + (size_t)off * fl, src, (size_t)nc * fl * sizeof(float),
+                              out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, float* pca_out, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!features || !pca_out) return fail(CS_ERR_INVALID, "features/pca_out is NULL");
+    if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_scaler_pca needs detector parameters");
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    if ((rc = ensure_workspace(m, ch, false))) return rc;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* f;
+        if ((rc = stage_in(m, features, in_kind, off, nc, (size_t)m->F, m->featE, &f))) return rc;
+        LAUNCH(K_SCALER_PCA, nc,
+               launch_scaler_pca(f, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
+                                 m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+        HIPCHK(hipMemcpyAsync(pca_out + (size_t)off * m->C, m->pca.p, (size_t)nc * m->C * sizeof(float),
+                              out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, double* cons_dec, double* mod_dec, int out_kind)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!pca) return fail(CS_ERR_INVALID, "pca is NULL");
+    if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
+    if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_svm_decision needs detector parameters");
+    const int64_t ch = n < m->chunk ? n : m->chunk;
+    if ((rc = ensure_workspace(m, ch, false))) return rc;
+    double* outs[2] = {cons_dec, mod_dec};
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        const float* p;
+        if ((rc = stage_in(m, pca, in_kind, off, nc, (size_t)m->C, m->pca, &p))) return rc;
+        for (int d = 0; d < 2; ++d) {
+            if (!outs[d]) continue;
+            LAUNCH(K_SVM, nc,
+                   launch_ocsvm(p, m->C, m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(), m->svm[d].nsv,
+                                m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
+            HIPCHK(hipMemcpyAsync(outs[d] + off, m->dec[d].p, (size_t)nc * sizeof(double),
+                                  out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
+        }
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return end_call(m);
+}
+
+int cs_synth_crops(cs_model* m, uint64_t seed, int64_t first_cell, int64_t n, int32_t npix, float* out_device)
+{
+    int rc = begin_call(m);
+    if (rc) return rc;
+    if (n < 0 || npix <= 0) return fail(CS_ERR_INVALID, "n/npix invalid");
+    if (n == 0) return CS_OK;
+    if (!out_device) return fail(CS_ERR_INVALID, "out_device is NULL");
+    LAUNCH(K_SYNTH, n, launch_synth(seed, first_cell, n, npix, out_device, m->stream));
+    return end_call(m);
+}
+
+// ---- measurement --------------------------------------------------------------------
+int cs_profile_enable(cs_model* m, int on)
+{
+    if (!m) return fail(CS_ERR_INVALID, "model handle is NULL");
+    m->prof = on != 0;
+    return CS_OK;
+}
+
+int cs_profile_reset(cs_model* m)
+{
+    if (!m) return fail(CS_ERR_INVALID, "model handle is NULL");
+    for (int k = 0; k < K_COUNT; ++k) { m->prof_ms[k] = 0; m->prof_launches[k] = 0; m->prof_cells[k] = 0; }
+    return CS_OK;
+}
+
+int cs_profile_kernel_count(void) { return K_COUNT; }
+
+const char* cs_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int cs_profile_get(cs_model* m, int k, double* total_ms, int64_t* launches, int64_t* cells, double* flops)
+{
+    if (!m || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
+    if (total_ms) *total_ms = m->prof_ms[k];
+    if (launches) *launches = m->prof_launches[k];
+    if (cells) *cells = m->prof_cells[k];
+    if (flops) {
+        double per_cell = 0.0;
+        if (k <= K_CONV7_ERR) per_cell = 2.0 * kLayerMacs[k];
+        else if (k == K_SCALER_PCA) per_cell = 2.0 * (double)m->F * m->C;
+        else if (k == K_SVM) per_cell = 0.0;  // fp64, reported separately
+        *flops = per_cell * (double)m->prof_cells[k];
+    }
+    return CS_OK;
+}
+
+}  // extern "C"

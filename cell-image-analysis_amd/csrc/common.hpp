@@ -1,0 +1,63 @@
+// Shared declarations for libcellscreen's HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Geometry of one conv layer of the reference graph (CAE_improved_modeltrain.py:191-216)
+// as the kernels see it.  H, W: conv grid (= conv output, pre-pool) size.
+struct LayerGeom {
+    int H, W, cin, cout;
+    bool pool;   // MaxPooling2D follows (encoder)
+    bool ups;    // the stored input is (H/2, W/2): UpSampling2D precedes this conv
+    bool last;   // sigmoid output conv
+};
+
+// Kernel families, for cs_profile_*.
+enum KernelId {
+    K_CONV1 = 0, K_CONV2, K_CONV3, K_CONV4, K_CONV5, K_CONV6, K_CONV7_ERR,
+    K_SCALER_PCA, K_SVM, K_FINALIZE, K_SYNTH, K_COUNT
+};
+
+// ---- launchers (each enqueues on `stream`, returns hipGetLastError()) -------------
+// conv layers 1..6 of the 64x64 reference graph; `layer` is 0-based.
+// in/out NHWC fp32; wfrag = MFMA B-operand fragments built by pack_conv_fragments();
+// ep = [3][cout] {bias, bn_scale, bn_shift}.
+hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, const float* ep,
+                            float* out, int64_t n_cells, hipStream_t stream);
+// Host-side packing of HWIO weights into the per-lane B fragments of launch_conv_mfma.
+// Returns the number of floats written (or required if dst == nullptr).
+size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);
+
+// conv7 + sigmoid + per-cell squared/absolute error partial sums.
+// a6: [n][32][32][32]; x: [n][64][64]; w7_host: HOST pointer, HWIO [3][3][32][1] (passed to
+// the kernel by value); errpart: [n][4][2];
+// recon (may be null): [n][64][64].
+hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_host, float b7,
+                            float* errpart, float* recon, int64_t n_cells, hipStream_t stream);
+
+// scaler.transform + pca.transform.  comps_pad: [cpad][fpad], zero beyond [C][F];
+// cpad % 16 == 0, fpad % 512 == 0.
+hipError_t launch_scaler_pca(const float* feat, const float* center, const double* scale,
+                             const float* comps_pad, const float* mean_proj, int F, int fpad, int C,
+                             int cpad, float* pca_out, int64_t n_cells, hipStream_t stream);
+
+// One-class SVM decision for one detector.  svT: [D][nsv_pad] (transposed, zero padded),
+// coef: [nsv_pad] (zero padded).  dec[n] = sum - rho.
+hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* coef, int nsv,
+                        int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
+                        hipStream_t stream);
+
+// errpart -> mse/mae ; dec -> score (= -dec) and pred.
+hipError_t launch_finalize(const float* errpart, int nparts, int npix, const double* dec_c,
+                           const double* dec_m, float* mse, float* mae, double* score_c,
+                           double* score_m, int8_t* pred_c, int8_t* pred_m, int64_t n_cells,
+                           hipStream_t stream);
+
+hipError_t launch_synth(uint64_t seed, int64_t first_cell, int64_t n, int npix, float* out,
+                        hipStream_t stream);
+
+}  // namespace cs

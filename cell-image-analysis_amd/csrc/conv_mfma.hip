@@ -1,0 +1,306 @@
+// conv_mfma.hip -- 3x3 'same' conv + bias + ReLU + BatchNorm(inference) [+ 2x2 max-pool]
+// for conv layers 1..6 of the reference autoencoder (CAE_improved_modeltrain.py:191-214)
+// as an exact-fp32 MFMA implicit GEMM on gfx950.
+//
+// Mapping (v_mfma_f32_16x16x4_f32: D[16 pixels][16 couts] += A[16 pixels][4 k] * B[4 k][16 couts]):
+//   M = output pixels (a tile is 16 consecutive pixels of the conv grid),
+//   N = output channels (a wave owns one 16-channel slice),
+//   K = 9 taps x cin, walked in (tap, 16-channel block, 4 x 4-channel quads) order.
+// The B operand (the wave's [K x 16] weight slice, 72 or 144 values per lane) stays in
+// VGPRs for the lifetime of the persistent workgroup: weights never touch LDS, so LDS
+// only holds the activation strip and several workgroups share a CU, overlapping one
+// workgroup's staging/epilogue with another's MFMAs.
+// The A operand is read from an NHWC strip staged in LDS with a zero halo; the pixel
+// stride is padded by 16 B so the 16 pixels of a ds_read_b128 land on distinct 16-B
+// bank slots.  For the decoder layers the strip is kept at the stored (half) resolution
+// and UpSampling2D(2x2, nearest) is a `>> 1` in the A-operand address.
+// Accumulation is a k-ordered fp32 fma chain (the MFMA's exact semantics), one rounding
+// per product, bias added after the sum -- same numerics class as the fp32 oracle.
+#include "common.hpp"
+
+namespace cs {
+
+template <int H_, int W_, int CIN_, int COUT_, bool POOL_, bool UPS_, int SR_, int WPS_>
+struct ConvCfg {
+    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_;
+    static constexpr bool POOL = POOL_, UPS = UPS_;
+    static constexpr int NSL = COUT / 16;            // 16-channel output slices (= waves along N)
+    static constexpr int NMG = 4 / NSL;              // wave groups along M
+    static constexpr int KQ = CIN / 16;              // 16-channel K blocks per tap (0 when CIN == 1)
+    static constexpr int NB = (CIN == 1) ? 3 : 9 * KQ * 4;  // B fragment registers per lane
+    static constexpr int HS = UPS ? H / 2 : H;       // stored input size
+    static constexpr int WS = UPS ? W / 2 : W;
+    static constexpr int R = UPS ? SR / 2 + 2 : SR + 2;     // staged rows (incl. halo)
+    static constexpr int WP = WS + 2;                // staged cols (incl. halo)
+    static constexpr int PS = (CIN == 1) ? 1 : CIN + 4;     // floats per staged pixel
+    static constexpr int LDS_BYTES = R * WP * PS * 4;
+    static constexpr int NSTRIP = H / SR;
+    static constexpr int TPR = (W >= 16) ? W / 16 : 1;      // tiles per conv row (W >= 16)
+    static constexpr int TILES = SR * W / 16;
+    static constexpr int NPAIR = TILES / 2;
+    static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
+    static_assert(COUT % 16 == 0 && (NSL == 2 || NSL == 4), "cout must be 32 or 64");
+    static_assert(CIN == 1 || CIN % 16 == 0, "cin must be 1 or a multiple of 16");
+    static_assert(!POOL || W >= 16, "pooled layers need whole-row tiles");
+    static_assert(!UPS || W >= 16, "upsampled layers need whole-row tiles");
+    static_assert(TILES % 2 == 0 && NPAIR % NMG == 0, "strip must split into tile pairs");
+    static_assert(H % SR == 0 && SR % 2 == 0, "strip rows");
+};
+
+// Strip-local conv-grid coordinates of pixel `i` (0..15) of tile `t`.
+template <class C>
+__device__ __forceinline__ void tile_pixel(int t, int i, int& py, int& px)
+{
+    if constexpr (C::W >= 16) {
+        py = t / C::TPR;
+        px = (t % C::TPR) * 16 + i;
+    } else {  // W == 8: a tile is two rows of eight
+        py = 2 * t + (i >> 3);
+        px = i & 7;
+    }
+}
+
+// Byte address in the staged strip of channel block `kq` of the input pixel that tap
+// (dy,dx) of conv pixel (py,px) reads.
+template <class C>
+__device__ __forceinline__ int a_addr(int py, int px, int kq, int tap)
+{
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    if constexpr (C::UPS) {
+        const int r = ((py + dy) >> 1) + 1;   // arithmetic shift: -1 -> halo row 0
+        const int c = ((px + dx) >> 1) + 1;
+        return (r * C::WP + c) * (C::PS * 4) + kq * 16;
+    } else {
+        return ((py + dy + 1) * C::WP + (px + dx + 1)) * (C::PS * 4) + kq * 16;
+    }
+}
+
+__device__ __forceinline__ float relu_bn(float v, float bias, float s, float t)
+{
+    v += bias;
+    v = fmaxf(v, 0.0f);
+    return fmaf(v, s, t);
+}
+
+template <class C>
+__global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wfrag, const float* __restrict__ ep,
+    float* __restrict__ out, long n_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsl = wave % C::NSL;   // output-channel slice of this wave
+    const int mg = wave / C::NSL;    // tile-pair group of this wave
+    const int li = lane & 15;        // A: pixel in tile / B,D: channel in slice
+    const int kq = lane >> 4;        // A,B: k within the MFMA / D: pixel quad
+
+    // B fragments: this wave's [K x 16] weight slice, resident in registers.
+    float B[C::NB];
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) B[s] = wfrag[((size_t)nsl * C::NB + s) * 64 + lane];
+
+    const int co = nsl * 16 + li;
+    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+
+    // conv1: per-lane tap of each of the 3 K steps (k = 4 s + kq; k >= 9 is zero padding)
+    int toff[3];
+    bool tval[3];
+    if constexpr (C::CIN == 1) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + kq;
+            tval[s] = k < 9;
+            const int kk = tval[s] ? k : 0;
+            toff[s] = ((kk / 3) * C::WP + (kk % 3)) * 4;
+        }
+    }
+
+    const long total = n_cells * C::NSTRIP;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long cell = item / C::NSTRIP;
+        const int strip = (int)(item % C::NSTRIP);
+        const int y0 = strip * C::SR;
+
+        // ---- stage the strip (with zero halo) ------------------------------------
+        {
+            const int ybase = C::UPS ? (y0 / 2 - 1) : (y0 - 1);
+            const float* src = in + (size_t)cell * C::HS * C::WS * C::CIN;
+            if constexpr (C::CIN == 1) {
+                constexpr int TOT = C::R * C::WP;
+                for (int idx = tid; idx < TOT; idx += 256) {
+                    const int r = idx / C::WP, c = idx % C::WP;
+                    const int sy = ybase + r, sx = c - 1;
+                    float v = 0.0f;
+                    if (sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS) v = src[sy * C::WS + sx];
+                    *(float*)(smem + idx * 4) = v;
+                }
+            } else {
+                constexpr int C4 = C::CIN / 4;
+                constexpr int TOT = C::R * C::WP * C4;
+#pragma unroll 4
+                for (int idx = tid; idx < TOT; idx += 256) {
+                    const int pix = idx / C4, c4 = idx % C4;
+                    const int r = pix / C::WP, c = pix % C::WP;
+                    const int sy = ybase + r, sx = c - 1;
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS)
+                        v = *(const f32x4*)(src + ((size_t)sy * C::WS + sx) * C::CIN + c4 * 4);
+                    *(f32x4*)(smem + (pix * C::PS + c4 * 4) * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- tile pairs ----------------------------------------------------------
+        for (int p = mg; p < C::NPAIR; p += C::NMG) {
+            int t0, t1;
+            if constexpr (C::POOL) {  // vertical pool partners: same columns, rows 2r and 2r+1
+                const int ry = 2 * (p / C::TPR), xb = p % C::TPR;
+                t0 = ry * C::TPR + xb;
+                t1 = (ry + 1) * C::TPR + xb;
+            } else {
+                t0 = 2 * p;
+                t1 = 2 * p + 1;
+            }
+            int py0, px0, py1, px1;
+            tile_pixel<C>(t0, li, py0, px0);
+            tile_pixel<C>(t1, li, py1, px1);
+
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (C::CIN == 1) {
+                const int b0 = (py0 * C::WP + px0) * 4, b1 = (py1 * C::WP + px1) * 4;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    float a0 = *(const float*)(smem + b0 + toff[s]);
+                    float a1 = *(const float*)(smem + b1 + toff[s]);
+                    a0 = tval[s] ? a0 : 0.0f;
+                    a1 = tval[s] ? a1 : 0.0f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ad0 = a_addr<C>(py0, px0, kq, tap);
+                    const int ad1 = a_addr<C>(py1, px1, kq, tap);
+#pragma unroll
+                    for (int q = 0; q < C::KQ; ++q) {
+                        const f32x4 a0 = *(const f32x4*)(smem + ad0 + q * 64);
+                        const f32x4 a1 = *(const f32x4*)(smem + ad1 + q * 64);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float b = B[(tap * C::KQ + q) * 4 + j];
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc1, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+
+            // ---- epilogue: D[row = 4*kq + r][col = li] -> bias, relu, BN, (pool), store
+            if constexpr (C::POOL) {
+                // lane holds pixels x = xq..xq+3 of rows (y, y+1); t0/t1 share columns
+                int qy, qx;
+                tile_pixel<C>(t0, 4 * kq, qy, qx);
+                const int yo = (y0 + qy) >> 1;
+                const int xo = qx >> 1;
+                float e0[4], e1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[r] = relu_bn(acc0[r], bias, bns, bnt);
+                    e1[r] = relu_bn(acc1[r], bias, bns, bnt);
+                }
+                float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
+                o[0] = fmaxf(fmaxf(e0[0], e0[1]), fmaxf(e1[0], e1[1]));
+                o[C::COUT] = fmaxf(fmaxf(e0[2], e0[3]), fmaxf(e1[2], e1[3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int qy, qx;
+                    tile_pixel<C>(t0, 4 * kq + r, qy, qx);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] =
+                        relu_bn(acc0[r], bias, bns, bnt);
+                    tile_pixel<C>(t1, 4 * kq + r, qy, qx);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] =
+                        relu_bn(acc1[r], bias, bns, bnt);
+                }
+            }
+        }
+        __syncthreads();  // strip is re-staged by the next item
+    }
+}
+
+//                      H   W  CIN COUT POOL   UPS   SR WPS
+using CfgL1 = ConvCfg<64, 64,  1, 32, true,  false, 16, 4>;   // CAE...:191-193
+using CfgL2 = ConvCfg<32, 32, 32, 64, true,  false,  8, 3>;   // :195-197
+using CfgL3 = ConvCfg<16, 16, 64, 32, true,  false,  8, 2>;   // :199-201 -> encoded 8x8x32
+using CfgL4 = ConvCfg< 8,  8, 32, 32, false, false,  8, 3>;   // :204-205
+using CfgL5 = ConvCfg<16, 16, 32, 64, false, true,  16, 3>;   // :206-209 (reads up(a4))
+using CfgL6 = ConvCfg<32, 32, 64, 32, false, true,   8, 2>;   // :210-213 (reads up(a5))
+
+template <class C>
+static hipError_t launch_cfg(const float* in, const float* wfrag, const float* ep, float* out,
+                             int64_t n_cells, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<C>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long total = (long)n_cells * C::NSTRIP;
+    if (total <= 0) return hipSuccess;
+    const long max_blocks = 256L * 4;  // persistent: a few workgroups per CU
+    const unsigned grid = (unsigned)(total < max_blocks ? total : max_blocks);
+    hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, in, wfrag, ep,
+                       out, (long)n_cells);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, const float* ep,
+                            float* out, int64_t n_cells, hipStream_t stream)
+{
+    switch (layer) {
+        case 0: return launch_cfg<CfgL1>(in, wfrag, ep, out, n_cells, stream);
+        case 1: return launch_cfg<CfgL2>(in, wfrag, ep, out, n_cells, stream);
+        case 2: return launch_cfg<CfgL3>(in, wfrag, ep, out, n_cells, stream);
+        case 3: return launch_cfg<CfgL4>(in, wfrag, ep, out, n_cells, stream);
+        case 4: return launch_cfg<CfgL5>(in, wfrag, ep, out, n_cells, stream);
+        case 5: return launch_cfg<CfgL6>(in, wfrag, ep, out, n_cells, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// wfrag[nsl][s][lane]: the value lane (li = lane & 15, kq = lane >> 4) feeds as B[k = kq][n = li]
+// of K step s.  cin >= 16: s = (tap*KQ + q)*4 + j reads input channel 16q + 4kq + j.
+// cin == 1: s in 0..2 reads tap 4s + kq (zero for the padded taps 9..11).
+size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst)
+{
+    const int nsl_n = cout / 16;
+    const int kq_n = cin / 16;
+    const int nb = (cin == 1) ? 3 : 9 * kq_n * 4;
+    const size_t total = (size_t)nsl_n * nb * 64;
+    if (!dst) return total;
+    for (int nsl = 0; nsl < nsl_n; ++nsl)
+        for (int s = 0; s < nb; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int li = lane & 15, kq = lane >> 4;
+                const int co = nsl * 16 + li;
+                float v;
+                if (cin == 1) {
+                    const int k = 4 * s + kq;
+                    v = (k < 9) ? hwio[(size_t)k * cout + co] : 0.0f;
+                } else {
+                    const int j = s & 3, q = (s >> 2) % kq_n, tap = (s >> 2) / kq_n;
+                    const int ci = 16 * q + 4 * kq + j;
+                    v = hwio[((size_t)tap * cin + ci) * cout + co];
+                }
+                dst[((size_t)nsl * nb + s) * 64 + lane] = v;
+            }
+    return total;
+}
+
+}  // namespace cs

@@ -1,0 +1,136 @@
+// conv_out.hip -- the output conv of the autoencoder fused with the reconstruction error:
+// UpSampling2D(2x2) -> Conv2D(1, 3x3, 'same', sigmoid)          CAE_improved_modeltrain.py:214-216
+// -> sum (x - r)^2 and sum |x - r| per cell                      improved_detection.py:126-127
+// The reconstruction itself is never written to HBM unless a debug pointer asks for it.
+//
+// cout = 1, so this is a per-pixel 288-term dot product, not a GEMM: a VALU kernel.
+// One thread owns one pixel of the stored (32x32) a6 grid = a 2x2 block of output pixels;
+// nearest upsampling means all 4 outputs read the same 3x3 neighbourhood of a6, so each
+// 16-B LDS read of 4 channels feeds up to 16 FMAs.  Weights arrive as a by-value kernel
+// argument, i.e. scalar loads from the kernarg segment into SGPRs.
+#include "common.hpp"
+
+namespace cs {
+
+namespace {
+constexpr int C7_CIN = 32;
+constexpr int C7_HS = 32, C7_WS = 32;        // stored a6 size
+constexpr int C7_SR = 8;                     // a6 rows per workgroup (16 output rows)
+constexpr int C7_R = C7_SR + 2, C7_WP = C7_WS + 2, C7_PS = C7_CIN + 4;
+constexpr int C7_LDS = C7_R * C7_WP * C7_PS * 4;
+constexpr int C7_NSTRIP = C7_HS / C7_SR;     // 4 partial sums per cell
+
+struct W7 { float w[9 * C7_CIN]; };          // [tap][cin]
+
+__global__ __launch_bounds__(256, 2) void conv7_err_kernel(
+    const float* __restrict__ a6, const float* __restrict__ x, W7 wt, float b7,
+    float* __restrict__ errpart, float* __restrict__ recon, long n_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float (*red)[4] = (float (*)[4])(smem + C7_LDS);  // 2 x 4 wave sums, after the strip
+    const int tid = threadIdx.x;
+    const long total = n_cells * C7_NSTRIP;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long cell = item / C7_NSTRIP;
+        const int strip = (int)(item % C7_NSTRIP);
+        const int y0 = strip * C7_SR;  // first a6 row of the strip
+
+        // stage a6 rows y0-1 .. y0+SR with zero halo
+        {
+            constexpr int C4 = C7_CIN / 4;
+            constexpr int TOT = C7_R * C7_WP * C4;
+            const float* src = a6 + (size_t)cell * C7_HS * C7_WS * C7_CIN;
+#pragma unroll 4
+            for (int idx = tid; idx < TOT; idx += 256) {
+                const int pix = idx / C4, c4 = idx % C4;
+                const int r = pix / C7_WP, c = pix % C7_WP;
+                const int sy = y0 - 1 + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < C7_HS && sx >= 0 && sx < C7_WS)
+                    v = *(const f32x4*)(src + ((size_t)sy * C7_WS + sx) * C7_CIN + c4 * 4);
+                *(f32x4*)(smem + (pix * C7_PS + c4 * 4) * 4) = v;
+            }
+        }
+        __syncthreads();
+
+        const int ly = tid >> 5, lx = tid & 31;  // a6 pixel (y0 + ly, lx)
+        float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll 1
+        for (int q = 0; q < C7_CIN / 4; ++q) {
+            f32x4 nb[3][3];
+#pragma unroll
+            for (int ry = 0; ry < 3; ++ry)
+#pragma unroll
+                for (int rx = 0; rx < 3; ++rx)
+                    nb[ry][rx] = *(const f32x4*)(smem + (((ly + ry) * C7_WP + lx + rx) * C7_PS + q * 4) * 4);
+            // output (2y+a, 2x+b), tap (dy,dx) reads a6[y + ((a+dy)>>1)][x + ((b+dx)>>1)]
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int ny = ((a + dy) >> 1) + 1, nx = ((b + dx) >> 1) + 1;
+                            const int tap = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[a][b] = fmaf(nb[ny][nx][j], wt.w[tap * C7_CIN + q * 4 + j], acc[a][b]);
+                        }
+        }
+
+        // sigmoid, error terms
+        float s2 = 0.0f, s1 = 0.0f;
+        const int Y = 2 * (y0 + ly), X = 2 * lx;
+        const float* xc = x + (size_t)cell * 64 * 64;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float v = acc[a][b] + b7;
+                const float r = 1.0f / (1.0f + expf(-v));
+                const float d = xc[(Y + a) * 64 + X + b] - r;
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+                if (recon) recon[(size_t)cell * 64 * 64 + (Y + a) * 64 + X + b] = r;
+            }
+        // deterministic block reduction: wave shuffle tree, then 4 wave sums in order
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_down(s2, off, 64);
+            s1 += __shfl_down(s1, off, 64);
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = s1; }
+        __syncthreads();
+        if (tid == 0) {
+            errpart[(cell * C7_NSTRIP + strip) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            errpart[(cell * C7_NSTRIP + strip) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_host, float b7,
+                            float* errpart, float* recon, int64_t n_cells, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv7_err_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS + 32);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long total = (long)n_cells * C7_NSTRIP;
+    if (total <= 0) return hipSuccess;
+    W7 wt;
+    for (int i = 0; i < 9 * C7_CIN; ++i) wt.w[i] = w7_host[i];  // HWIO with cout = 1 is [tap][cin]
+    const long max_blocks = 256L * 6;
+    const unsigned grid = (unsigned)(total < max_blocks ? total : max_blocks);
+    hipLaunchKernelGGL(conv7_err_kernel, dim3(grid), dim3(256), C7_LDS + 32, stream, a6, x, wt, b7, errpart,
+                       recon, (long)n_cells);
+    return hipGetLastError();
+}
+
+}  // namespace cs

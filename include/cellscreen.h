@@ -1,0 +1,200 @@
+/*
+ * cellscreen.h -- C ABI of libcellscreen.so, the MI355X (gfx950) cell-crop
+ * anomaly-screening path.
+ *
+ * The reference (Kmatsuo57/cell-image-analysis) is two Python classes with no
+ * FFI; what this library replaces, entry point by entry point:
+ *
+ *   cs_model_load / cs_model_from_arrays
+ *        ProductionMutantScreening.load_trained_models    improved_detection.py:23-46
+ *        (the StarDist fetch at :44 is cell extraction, out of scope)
+ *   cs_screen
+ *        ProductionMutantScreening.compute_anomaly_scores improved_detection.py:117-153
+ *        = autoencoder.predict (:125) + per-cell MSE/MAE (:126-127) + encoder.predict
+ *          (:130-131) + scaler.transform (:134) + pca.transform (:135) + 2x OneClassSVM
+ *          predict / decision_function (:138-142) + score negation (:149-150)
+ *   cs_reconstruct
+ *        evaluate_reconstruction_quality numerics   CAE_improved_modeltrain.py:335-339
+ *   cs_encode
+ *        encoder.predict + flatten      improved_detection.py:130-131, CAE...:401-402
+ *   cs_layer_output, cs_scaler_pca, cs_svm_decision
+ *        stage-level taps used by the parity tests (oracle inputs to each stage)
+ *   cs_synth_crops
+ *        synthetic U[0,1) crops (no reference counterpart; benchmark/test input)
+ *
+ * Conventions
+ *   - Every function returns CS_OK (0) or a negative cs_status.  cs_last_error()
+ *     returns a thread-local message for the most recent failure on this thread.
+ *   - Handles are opaque, created and destroyed by the library.  One handle = one
+ *     device + one HIP stream + one workspace; a handle is not thread-safe, distinct
+ *     handles are independent.  No exceptions or C++ types cross the boundary.
+ *   - Every buffer passed in is caller-owned and borrowed for the duration of the call.
+ *     `*_kind` says where it lives: CS_MEM_HOST (pageable or pinned host memory) or
+ *     CS_MEM_DEVICE (memory of the handle's device, e.g. a torch tensor's data_ptr()).
+ *   - Calls are synchronous: outputs are complete when the call returns.
+ *   - Layouts: crops [n][H][W] fp32 (the trailing channel of 1 is implicit, as
+ *     np.expand_dims at improved_detection.py:122 adds it); conv kernels HWIO
+ *     [3][3][cin][cout] as Keras stores them; features [n][h*w*c] in (h,w,c) order
+ *     as the reshape at improved_detection.py:131 produces.
+ *   - There is NO CPU fallback: without a gfx950 device every compute entry point
+ *     returns CS_ERR_NO_DEVICE.
+ */
+#ifndef CELLSCREEN_H
+#define CELLSCREEN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+#define CS_MAX_CONV 16
+
+typedef enum cs_status {
+    CS_OK = 0,
+    CS_ERR_INVALID = -1,      /* bad argument (NULL, negative size, wrong shape) */
+    CS_ERR_IO = -2,           /* file missing / unreadable */
+    CS_ERR_FORMAT = -3,       /* malformed model file */
+    CS_ERR_NO_DEVICE = -4,    /* no usable gfx950 device */
+    CS_ERR_HIP = -5,          /* HIP runtime error (message in cs_last_error) */
+    CS_ERR_UNSUPPORTED = -6,  /* architecture / size this build has no kernel for */
+    CS_ERR_NOMEM = -7,
+    CS_ERR_NO_DETECTOR = -8   /* model was created without detector parameters */
+} cs_status;
+
+typedef enum cs_mem_kind { CS_MEM_HOST = 0, CS_MEM_DEVICE = 1 } cs_mem_kind;
+
+typedef struct cs_model cs_model;
+
+/* One conv autoencoder weight set (CAE_improved_modeltrain.py:184-229).
+ * n_conv convs; the first n_enc are each followed by BatchNormalization + MaxPooling2D,
+ * the next n_conv-n_enc-1 by BatchNormalization + UpSampling2D, the last has sigmoid.
+ * BN arrays are NULL for the last conv. */
+typedef struct cs_cae_weights {
+    int32_t height, width;            /* input crop size: 64, 64 */
+    int32_t n_conv, n_enc;            /* 7, 3 */
+    int32_t channels[CS_MAX_CONV];    /* filters of each conv: 32,64,32,32,64,32,1 */
+    const float *kernel[CS_MAX_CONV]; /* HWIO [3][3][cin][cout] */
+    const float *bias[CS_MAX_CONV];   /* [cout] */
+    const float *bn_gamma[CS_MAX_CONV];
+    const float *bn_beta[CS_MAX_CONV];
+    const float *bn_mean[CS_MAX_CONV];
+    const float *bn_var[CS_MAX_CONV];
+    float bn_eps;                     /* Keras default 1e-3 */
+} cs_cae_weights;
+
+/* One fitted OneClassSVM(kernel='rbf') (CAE_improved_modeltrain.py:420-427). */
+typedef struct cs_ocsvm_params {
+    int32_t n_sv;
+    const double *support_vectors;    /* [n_sv][n_components]  (sklearn support_vectors_) */
+    const double *dual_coef;          /* [n_sv]                (dual_coef_[0]) */
+    double gamma;                     /* _gamma */
+    double rho;                       /* -intercept_[0] == offset_[0] */
+} cs_ocsvm_params;
+
+/* RobustScaler + PCA + the two detectors (CAE_improved_modeltrain.py:408-427). */
+typedef struct cs_detector_params {
+    int32_t n_features;               /* 2048 */
+    int32_t n_components;             /* <= 100 */
+    const float *scaler_center;       /* [n_features]  center_  (float32) */
+    const double *scaler_scale;       /* [n_features]  scale_   (float64) */
+    const float *pca_components;      /* [n_components][n_features]  components_ */
+    const float *pca_mean_proj;       /* [n_components] = mean_ @ components_.T (float32) */
+    cs_ocsvm_params conservative;     /* nu = 0.05 */
+    cs_ocsvm_params moderate;         /* nu = 0.10 */
+} cs_detector_params;
+
+typedef struct cs_model_info {
+    int32_t height, width;
+    int32_t n_conv, n_enc;
+    int32_t feature_dim;              /* h*w*c of the encoded tensor */
+    int32_t n_components;
+    int32_t n_sv_conservative, n_sv_moderate;
+    int32_t shared_encoder;           /* 1: encoder weights are bit-identical to the
+                                         autoencoder's encoder half, so one pass serves both */
+    int32_t has_detector;
+    int32_t device_id;
+    int64_t chunk_cells;              /* cells processed per internal pass */
+} cs_model_info;
+
+/* ---- library / device ---------------------------------------------------------- */
+int cs_abi_version(void);
+const char *cs_status_string(int status);
+const char *cs_last_error(void);
+/* Number of visible HIP devices (0 if none).  Never fails. */
+int cs_device_count(void);
+
+/* ---- model --------------------------------------------------------------------- */
+/* Reads <model_dir>/cae.bin (+ detector.bin if present) in the native tensor-archive
+ * format written by cellscreen.model_io (see DESIGN.md "model_dir").
+ * Replaces load_trained_models, improved_detection.py:23-46. */
+int cs_model_load(const char *model_dir, int device_id, cs_model **out);
+
+/* autoencoder: weights of best_autoencoder.keras (improved_detection.py:28).
+ * encoder:     weights of encoder.keras (:29), n_conv = n_enc convs; NULL = same as the
+ *              autoencoder's encoder half.  The two files may differ
+ *              (CAE_improved_modeltrain.py:270-275 vs :300).
+ * detector:    may be NULL; then cs_screen returns CS_ERR_NO_DETECTOR. */
+int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights *encoder,
+                         const cs_detector_params *detector, int device_id, cs_model **out);
+void cs_model_free(cs_model *m);
+int cs_model_get_info(const cs_model *m, cs_model_info *info);
+/* Cells per internal pass (workspace ~0.4 MB per cell).  Default 4096. */
+int cs_model_set_chunk(cs_model *m, int64_t chunk_cells);
+
+/* ---- the hot path -------------------------------------------------------------- */
+/* compute_anomaly_scores, improved_detection.py:117-153, for n crops.
+ * Outputs (each may be NULL to skip), all length n:
+ *   mse, mae            reconstruction_mse / reconstruction_mae (float32)
+ *   cons_score, mod_score   -decision_function (float64; "higher = more anomalous", :149-150)
+ *   cons_pred, mod_pred     predict: +1 inlier / -1 anomaly (:138-139; libsvm dec > 0 ? 1 : -1)
+ * n == 0 is valid and touches nothing (the reference returns {} at :119-120). */
+int cs_screen(cs_model *m, const float *crops, int64_t n, int crops_kind,
+              float *mse, float *mae, double *cons_score, double *mod_score,
+              int8_t *cons_pred, int8_t *mod_pred, int out_kind);
+
+/* autoencoder.predict + MSE/MAE (CAE_improved_modeltrain.py:335-339).
+ * recon [n][H][W] may be NULL. */
+int cs_reconstruct(cs_model *m, const float *crops, int64_t n, int crops_kind,
+                   float *recon, float *mse, float *mae, int out_kind);
+
+/* encoder.predict + reshape (improved_detection.py:130-131).
+ * which = 0: the autoencoder's encoder half; 1: the encoder.keras weight set. */
+int cs_encode(cs_model *m, const float *crops, int64_t n, int crops_kind, int which,
+              float *features, int out_kind);
+
+/* ---- stage taps for parity tests ------------------------------------------------ */
+/* Output of conv `layer` (0-based) of the autoencoder after its relu/BN/pool (the tensor
+ * the next conv reads), NHWC; for the last conv the sigmoid output.  out: n * layer size. */
+int cs_layer_output(cs_model *m, const float *crops, int64_t n, int crops_kind, int layer,
+                    float *out, int out_kind);
+/* scaler.transform + pca.transform on caller-supplied features [n][n_features]. */
+int cs_scaler_pca(cs_model *m, const float *features, int64_t n, int in_kind,
+                  float *pca_out /* [n][n_components] */, int out_kind);
+/* decision_function of both detectors on caller-supplied PCA vectors [n][n_components]. */
+int cs_svm_decision(cs_model *m, const float *pca, int64_t n, int in_kind,
+                    double *cons_dec, double *mod_dec, int out_kind);
+
+/* ---- synthetic input ------------------------------------------------------------ */
+/* Fills out_device[n][npix] with U[0,1) fp32 from the counter-based generator keyed
+ * (seed, first_cell + i, pixel); bit-identical to oracle/cae_oracle.c:orc_synth_crops. */
+int cs_synth_crops(cs_model *m, uint64_t seed, int64_t first_cell, int64_t n, int32_t npix,
+                   float *out_device);
+
+/* ---- measurement ---------------------------------------------------------------- */
+/* When enabled, every kernel launch of this handle is bracketed by HIP events on the
+ * handle's stream; totals are per kernel family.  Adds a stream sync per call. */
+int cs_profile_enable(cs_model *m, int on);
+int cs_profile_reset(cs_model *m);
+int cs_profile_kernel_count(void);
+const char *cs_profile_kernel_name(int kernel_id);
+/* total_ms: summed device time; launches: number of launches; cells: cells processed;
+ * flops: algorithmic FLOPs of those launches (2 x MACs of the reference graph). */
+int cs_profile_get(cs_model *m, int kernel_id, double *total_ms, int64_t *launches,
+                   int64_t *cells, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELLSCREEN_H */

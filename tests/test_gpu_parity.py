@@ -1,0 +1,234 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs and against the committed golden vectors.  Run on the GPU box: -m gpu.
+Tolerances are the stated ones (helpers.py / SURVEY.md Appendix G); integer and
+bookkeeping results are bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from cellscreen import model_io, spec, synth
+from cellscreen.engine import Engine
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return synth.random_cae(seed=42)
+
+
+@pytest.fixture(scope="module")
+def det(golden_det):
+    return H.det_from_golden(golden_det)
+
+
+@pytest.fixture(scope="module")
+def engine(weights, det):
+    e = Engine.from_weights(weights, None, det)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def crops():
+    return np.concatenate([synth.synth_crops(42, 0, 40), synth.blob_crops(4, 8)])
+
+
+def test_native_library_is_loaded_and_on_gfx950(engine):
+    assert engine.info.shared_encoder == 1 and engine.info.has_detector == 1
+    assert engine.info.feature_dim == 2048 and engine.info.n_components == 100
+    maps = open("/proc/self/maps").read()
+    assert "libcellscreen.so" in maps
+
+
+def test_synth_crops_bit_exact(engine):
+    import torch
+    t = torch.empty((33, 64, 64), dtype=torch.float32, device="cuda")
+    engine.synth_crops(42, 123456, t)
+    assert np.array_equal(t.cpu().numpy(), oracle.synth_crops(42, 123456, 33))
+
+
+@pytest.mark.parametrize("layer", range(7))
+def test_each_layer_against_oracle(engine, weights, crops, layer):
+    ref = oracle.cae_forward(weights, crops, acc64=True, layers=True)["layers"][layer]
+    got = engine.layer_output(crops, layer)
+    if layer == 6:
+        got = got[..., 0] if got.ndim == 4 else got
+        ref = ref[..., 0]
+        assert np.abs(got.astype(np.float64) - ref).max() <= H.TOL_RECON
+    else:
+        H.assert_close_scaled(got, ref, 1e-5, f"layer {layer}")
+
+
+def test_golden_cae_vectors(golden_cae):
+    g = golden_cae
+    e = Engine.from_weights(H.cae_from_golden(g))
+    feats = e.encode(g["crops"], which=0)
+    H.assert_close_scaled(feats, g["features"], H.TOL_FEATURES, "golden features")
+    rec, mse, mae = e.reconstruct(g["crops"])
+    assert np.abs(rec.astype(np.float64) - g["recon"]).max() <= H.TOL_RECON
+    H.assert_rel(mse, g["mse"], H.TOL_ERR_REL, "golden mse")
+    H.assert_rel(mae, g["mae"], H.TOL_ERR_REL, "golden mae")
+    for l in range(6):
+        flat = e.layer_output(g["crops"], l).reshape(len(g["crops"]), -1).astype(np.float64)
+        H.assert_close_scaled(flat[:, :64], g[f"layer{l}_first64"], 1e-5, f"golden layer{l} head")
+        H.assert_rel(flat.sum(axis=1), g[f"layer{l}_sum"], 1e-5, f"golden layer{l} sum")
+    e.close()
+
+
+def test_golden_detector_stages(engine, det, golden_det):
+    g = golden_det
+    pca = engine.scaler_pca(g["test_features"])
+    H.assert_close_scaled(pca, g["pca"], H.TOL_STAGE, "scaler+pca stage vs sklearn")
+    dc, dm = engine.svm_decision(g["pca"])
+    for name, dec, p in (("cons", dc, det.conservative), ("mod", dm, det.moderate)):
+        tol = H.TOL_DEC_STAGE * np.abs(p.dual_coef).sum()
+        assert np.abs(dec - g[f"{name}_dec"]).max() <= tol, name
+        pred = np.where(dec > 0, 1, -1)
+        H.flags_agree(dec, pred, g[f"{name}_dec"], g[f"{name}_pred"], tol, name)
+
+
+def test_screen_end_to_end_against_oracle(engine, weights, det, crops):
+    ref = oracle.screen(weights, None, det, crops, acc64=True)
+    r = engine.screen(crops)
+    H.assert_rel(r["mse"], ref["mse"], H.TOL_ERR_REL, "mse")
+    H.assert_rel(r["mae"], ref["mae"], H.TOL_ERR_REL, "mae")
+    skipped = 0
+    for name, p in (("cons", det.conservative), ("mod", det.moderate)):
+        tol = H.TOL_DEC_E2E * np.abs(p.dual_coef).sum()
+        assert np.abs(r[f"{name}_score"] - ref[f"{name}_score"]).max() <= tol, name
+        assert r[f"{name}_pred"].dtype == np.int8 and set(np.unique(r[f"{name}_pred"])) <= {-1, 1}
+        skipped += H.flags_agree(-r[f"{name}_score"], r[f"{name}_pred"], ref[f"{name}_dec"], ref[f"{name}_pred"], tol, name)
+        # label is exactly the sign rule applied to the returned score (svm.cpp:2838)
+        assert np.array_equal(r[f"{name}_pred"], np.where(-r[f"{name}_score"] > 0, 1, -1))
+    print("labels within tolerance of 0 (not compared):", skipped)
+
+
+def test_separate_encoder_weight_set(weights, det, crops):
+    """encoder.keras != autoencoder's encoder half (CAE...:270-275 vs :300): features must come
+    from the encoder set, reconstruction errors from the autoencoder set."""
+    enc = synth.perturbed_encoder(weights)
+    e = Engine.from_weights(weights, enc, det)
+    assert e.info.shared_encoder == 0
+    x = crops[:12]
+    ref = oracle.screen(weights, enc, det, x, acc64=True)
+    r = e.screen(x)
+    H.assert_rel(r["mse"], ref["mse"], H.TOL_ERR_REL, "mse (autoencoder weights)")
+    H.assert_close_scaled(e.encode(x, which=1), ref["features"], H.TOL_FEATURES, "features (encoder.keras weights)")
+    fa = oracle.cae_forward(weights, x, acc64=True, want=("features",))["features"]
+    H.assert_close_scaled(e.encode(x, which=0), fa, H.TOL_FEATURES, "features (autoencoder half)")
+    tol = H.TOL_DEC_E2E * np.abs(det.conservative.dual_coef).sum()
+    assert np.abs(r["cons_score"] - ref["cons_score"]).max() <= tol
+    # identical weight sets are detected as shared
+    e2 = Engine.from_weights(weights, weights.encoder_half(), det)
+    assert e2.info.shared_encoder == 1
+    e.close(); e2.close()
+
+
+def test_chunking_and_ragged_sizes(engine, weights, det):
+    """Results must not depend on the internal chunk size; n = 0, 1 and non-multiples work."""
+    x = synth.synth_crops(5, 0, 37)
+    engine.set_chunk(4096)
+    base = engine.screen(x)
+    for ch in (1, 5, 16, 36, 37):
+        engine.set_chunk(ch)
+        r = engine.screen(x)
+        for k in base:
+            assert np.array_equal(r[k], base[k]), (ch, k)
+    engine.set_chunk(4096)
+    one = engine.screen(x[:1])
+    assert np.array_equal(one["mse"], base["mse"][:1]) and np.array_equal(one["cons_score"], base["cons_score"][:1])
+    empty = engine.screen(np.zeros((0, 64, 64), np.float32))
+    assert all(len(v) == 0 for v in empty.values())
+
+
+def test_device_resident_buffers_match_host_path(engine):
+    import torch
+    x = synth.synth_crops(8, 0, 50)
+    host = engine.screen(x)
+    xd = torch.from_numpy(x).cuda()
+    dev = engine.screen(xd)
+    for k in host:
+        assert dev[k].is_cuda
+        assert np.array_equal(dev[k].cpu().numpy(), host[k]), k
+
+
+def test_extreme_inputs(engine, weights):
+    """All-zero, all-one and a single bright pixel at each corner (zero padding at the borders)."""
+    x = np.zeros((6, 64, 64), np.float32)
+    x[1] = 1.0
+    x[2, 0, 0] = 1.0; x[3, 0, 63] = 1.0; x[4, 63, 0] = 1.0; x[5, 63, 63] = 1.0
+    ref = oracle.cae_forward(weights, x, acc64=True)
+    rec, mse, mae = engine.reconstruct(x)
+    assert np.abs(rec.astype(np.float64) - ref["recon"]).max() <= H.TOL_RECON
+    H.assert_rel(mse, ref["mse"], H.TOL_ERR_REL, "mse")
+    H.assert_close_scaled(engine.encode(x, which=0), ref["features"], H.TOL_FEATURES, "features")
+
+
+def test_negative_bn_scale(det):
+    """BN between ReLU and pool with negative gamma: pool must see BN output (SURVEY finding 2)."""
+    w = synth.random_cae(seed=5)
+    for l in range(6):
+        w.bn_gamma[l][::2] *= -1.0
+    e = Engine.from_weights(w)
+    x = synth.synth_crops(3, 0, 4)
+    ref = oracle.cae_forward(w, x, acc64=True)
+    H.assert_close_scaled(e.encode(x, which=0), ref["features"], H.TOL_FEATURES, "features, negative gamma")
+    _, mse, _ = e.reconstruct(x, want_recon=False)
+    H.assert_rel(mse, ref["mse"], H.TOL_ERR_REL, "mse, negative gamma")
+    e.close()
+
+
+def test_model_dir_load_and_csv_out(tmp_path, weights, det):
+    """model_dir-load / screen / CSV-out through the host mirror of the reference class."""
+    import pandas as pd
+    from cellscreen.screening import ProductionMutantScreening
+    mdir = str(tmp_path / "models")
+    model_io.save_model_dir(mdir, weights, None, det)
+    a = tmp_path / "strainA"; b = tmp_path / "strainB"
+    a.mkdir(); b.mkdir()
+    xa, xb = synth.synth_crops(1, 0, 9), synth.blob_crops(2, 6)
+    np.save(a / "f1.npy", xa[:4]); np.save(a / "f2.npy", xa[4:]); np.save(b / "g.npy", xb)
+    s = ProductionMutantScreening(mdir, file_pattern="*.npy")
+    results, detailed = s.screen_mutant_samples({"A": str(a), "B": str(b)}, str(tmp_path / "out"))
+    ref = oracle.screen(weights, None, det, xa, acc64=True)
+    H.assert_rel([d["mse"] for d in detailed[:9]], ref["mse"], H.TOL_ERR_REL, "csv mse")
+    assert [d["cell_id"] for d in detailed] == list(range(9)) + list(range(6))
+    assert results["A"]["total_cells"] == 9 and results["A"]["files_processed"] == 2
+    rate = np.mean(ref["cons_pred"] == -1)
+    assert abs(results["A"]["conservative_anomaly_rate"] - rate) <= 1 / 9 + 1e-12
+    df = pd.read_csv(tmp_path / "out" / "detailed_cell_results.csv")
+    assert tuple(df.columns) == spec.DETAIL_COLUMNS and len(df) == 15
+    sm = pd.read_csv(tmp_path / "out" / "screening_summary.csv", index_col=0)
+    assert tuple(sm.columns) == spec.SUMMARY_COLUMNS
+
+
+def test_full_size_properties(engine, weights, det):
+    """Size-independent properties at a large N (200k cells, device resident):
+    determinism, shard-concatenation equality, and oracle parity on a random sample."""
+    import torch
+    n = 200_000
+    x = torch.empty((n, 64, 64), dtype=torch.float32, device="cuda")
+    engine.synth_crops(42, 0, x)
+    engine.set_chunk(4096)
+    r1 = engine.screen(x)
+    r2 = engine.screen(x)
+    for k in r1:
+        assert torch.equal(r1[k], r2[k]), f"{k}: not deterministic"
+    # shards [0, n/2) and [n/2, n) concatenated == whole (the multi-GPU partition, section 8e)
+    h = n // 2
+    ra, rb = engine.screen(x[:h]), engine.screen(x[h:])
+    for k in r1:
+        assert torch.equal(torch.cat([ra[k], rb[k]]), r1[k]), f"{k}: shard concat differs"
+    idx = np.sort(np.random.default_rng(0).choice(n, 48, replace=False))
+    xs = np.stack([oracle.synth_crops(42, int(i), 1)[0] for i in idx])
+    assert np.array_equal(x[torch.from_numpy(idx).cuda()].cpu().numpy(), xs)
+    ref = oracle.screen(weights, None, det, xs, acc64=True)
+    H.assert_rel(r1["mse"].cpu().numpy()[idx], ref["mse"], H.TOL_ERR_REL, "sampled mse")
+    tol = H.TOL_DEC_E2E * np.abs(det.moderate.dual_coef).sum()
+    assert np.abs(r1["mod_score"].cpu().numpy()[idx] - ref["mod_score"]).max() <= tol
+    rate = float((r1["cons_pred"] == -1).float().mean())
+    assert 0.0 <= rate <= 1.0
