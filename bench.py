@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=1_000_000, help="crops per GPU per step")
-    ap.add_argument("--chunk", type=int, default=4096, help="cells per internal pass")
+    ap.add_argument("--chunk", type=int, default=16384, help="cells per internal pass")
     ap.add_argument("--train-cells", type=int, default=5000, help="synthetic crops the detector is fit on")
     ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,18 +53,21 @@ def cpu_baseline(weights, det, seed, sample):
     """Times the CPU oracle on a bounded sample of the same synthetic workload."""
     import numpy as np
     from oracle import oracle
-    threads = oracle.num_threads()
-    probe = oracle.synth_crops(seed, 0, 32)
-    oracle.screen(weights, None, det, probe[:8])                 # warm up threads / page in
+    # use the cores this process may actually run on (the GPU box gives a 1-GPU job a CPU share)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(oracle.num_threads(), avail))
+    oracle.set_num_threads(threads)
+    probe = oracle.synth_crops(seed, 0, 8 * threads)
+    oracle.screen(weights, None, det, probe[:threads])           # warm up threads / page in
     t0 = time.perf_counter()
     oracle.screen(weights, None, det, probe)
-    rate = 32 / (time.perf_counter() - t0)
-    n = sample if sample > 0 else int(min(8192, max(64, rate * 15)))
+    rate = len(probe) / (time.perf_counter() - t0)
+    n = sample if sample > 0 else int(min(65536, max(64, rate * 15)))
     x = oracle.synth_crops(seed, 0, n)
     t0 = time.perf_counter()
     r = oracle.screen(weights, None, det, x)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="cells/s", cores=threads, kind="port",
+    return dict(value=n / dt, unit="cells/s", cores=threads, kind="port", host_cpus_visible=avail,
                 sample=f"{n} crops of the same synthetic workload (seed {seed}, cells 0..{n - 1}), "
                        f"oracle/cae_oracle.c fp32 + fp64 SVM, OpenMP {threads} threads, {dt:.1f} s"), r, x
 

@@ -84,9 +84,9 @@ struct cs_model {
     bool has_det = false;
     int F = 0, fpad = 0, C = 0, cpad = 0;
     DevBuf center, scale, comps, mean_proj;
-    struct Svm { DevBuf svT, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
+    struct Svm { DevBuf sv, svT, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
     // workspace (per chunk)
-    int64_t chunk = 4096;
+    int64_t chunk = 16384;
     int64_t ws_cells = 0;
     DevBuf xin, act[6], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
     // profiling
@@ -178,12 +178,17 @@ static int pack_svm(cs_model::Svm& s, const cs_ocsvm_params& p, int D, const cha
     s.nsv_pad = (p.n_sv + 255) / 256 * 256;
     s.gamma = p.gamma;
     s.rho = p.rho;
-    std::vector<double> svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0);
+    std::vector<double> sv((size_t)D * s.nsv_pad, 0.0), svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0);
     for (int i = 0; i < p.n_sv; ++i) {
         coef[i] = p.dual_coef[i];
-        for (int d = 0; d < D; ++d) svT[(size_t)d * s.nsv_pad + i] = p.support_vectors[(size_t)i * D + d];
+        for (int d = 0; d < D; ++d) {
+            sv[(size_t)i * D + d] = p.support_vectors[(size_t)i * D + d];
+            svT[(size_t)d * s.nsv_pad + i] = p.support_vectors[(size_t)i * D + d];
+        }
     }
-    int rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
+    int rc = upload(s.sv, sv.data(), sv.size() * sizeof(double));
+    if (rc) return rc;
+    rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
     if (rc) return rc;
     return upload(s.coef, coef.data(), coef.size() * sizeof(double));
 }
@@ -550,7 +555,7 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
                              m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
     for (int d = 0; d < 2; ++d)
         LAUNCH(K_SVM, nc,
-               launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(),
+               launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].sv.as<double>(), m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(),
                             m->svm[d].nsv, m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho,
                             m->dec[d].as<double>(), nc, m->stream));
     LAUNCH(K_FINALIZE, nc,
@@ -728,7 +733,7 @@ int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, doubl
         for (int d = 0; d < 2; ++d) {
             if (!outs[d]) continue;
             LAUNCH(K_SVM, nc,
-                   launch_ocsvm(p, m->C, m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(), m->svm[d].nsv,
+                   launch_ocsvm(p, m->C, m->svm[d].sv.as<double>(), m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(), m->svm[d].nsv,
                                 m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
             HIPCHK(hipMemcpyAsync(outs[d] + off, m->dec[d].p, (size_t)nc * sizeof(double),
                                   out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));

@@ -45,10 +45,10 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
                              const float* comps_pad, const float* mean_proj, int F, int fpad, int C,
                              int cpad, float* pca_out, int64_t n_cells, hipStream_t stream);
 
-// One-class SVM decision for one detector.  svT: [D][nsv_pad] (transposed, zero padded),
-// coef: [nsv_pad] (zero padded).  dec[n] = sum - rho.
-hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* coef, int nsv,
-                        int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
+// One-class SVM decision for one detector.  sv: [nsv_pad][D] row-major, svT: [D][nsv_pad]
+// (transposed), coef: [nsv_pad]; all zero padded.  dec[n] = sum - rho.
+hipError_t launch_ocsvm(const float* pca, int D, const double* sv, const double* svT, const double* coef,
+                        int nsv, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
                         hipStream_t stream);
 
 // errpart -> mse/mae ; dec -> score (= -dec) and pred.

@@ -18,11 +18,27 @@
 // per product, bias added after the sum -- same numerics class as the fp32 oracle.
 #include "common.hpp"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace cs {
 
-template <int H_, int W_, int CIN_, int COUT_, bool POOL_, bool UPS_, int SR_, int WPS_>
+// Strip staging modes (how the next strip's HBM/L2 latency is hidden behind the MFMA loop):
+//   STAGE_PF  the whole next strip is loaded into registers before the MFMA loop of the current
+//             item and written to LDS after it (small strips / kernels with registers to spare);
+//   STAGE_DB  two LDS strip buffers; every tile-pair iteration loads a slice of the NEXT strip at
+//             its top and writes it to the other buffer at its bottom (a few registers in flight,
+//             one barrier per item) -- for the register-heavy layers (cin = 64: 144 weight VGPRs).
+// Measured on MI355X (round 1): with the strip staged synchronously between items the
+// co-resident workgroups did not hide it (conv3 lost 23 %, conv2/conv6 8 % of the matrix pipe
+// to it); a start-up stagger of the workgroups and static per-slot s_setprio changed nothing;
+// conv2 needs 3 waves/SIMD (it has half the MFMAs per tile pair of the cin = 64 layers), which
+// is why it uses STAGE_PF on 4-row strips rather than STAGE_DB.
+enum { STAGE_PF = 1, STAGE_DB = 2 };
+
+template <int H_, int W_, int CIN_, int COUT_, bool POOL_, bool UPS_, int SR_, int WPS_, int MODE_>
 struct ConvCfg {
-    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_;
+    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_, MODE = MODE_;
     static constexpr bool POOL = POOL_, UPS = UPS_;
     static constexpr int NSL = COUT / 16;            // 16-channel output slices (= waves along N)
     static constexpr int NMG = 4 / NSL;              // wave groups along M
@@ -33,18 +49,25 @@ struct ConvCfg {
     static constexpr int R = UPS ? SR / 2 + 2 : SR + 2;     // staged rows (incl. halo)
     static constexpr int WP = WS + 2;                // staged cols (incl. halo)
     static constexpr int PS = (CIN == 1) ? 1 : CIN + 4;     // floats per staged pixel
-    static constexpr int LDS_BYTES = R * WP * PS * 4;
+    static constexpr int STRIP_BYTES = (R * WP * PS * 4 + 15) / 16 * 16;
+    static constexpr int LDS_BYTES = STRIP_BYTES * (MODE == STAGE_DB ? 2 : 1);
     static constexpr int NSTRIP = H / SR;
     static constexpr int TPR = (W >= 16) ? W / 16 : 1;      // tiles per conv row (W >= 16)
     static constexpr int TILES = SR * W / 16;
     static constexpr int NPAIR = TILES / 2;
+    static constexpr int PPW = NPAIR / NMG;          // tile pairs per wave per item
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
+    static constexpr int C4 = (CIN == 1) ? 1 : CIN / 4;     // staged elements (16 B; 4 B for conv1) per pixel
+    static constexpr int TOT = R * WP * C4;          // staged elements per strip
+    static constexpr int NLD = (TOT + 255) / 256;    // per-thread loads per strip
+    static constexpr int LPP = (NLD + PPW - 1) / PPW;       // per-thread loads per pair iteration (STAGE_DB)
     static_assert(COUT % 16 == 0 && (NSL == 2 || NSL == 4), "cout must be 32 or 64");
     static_assert(CIN == 1 || CIN % 16 == 0, "cin must be 1 or a multiple of 16");
     static_assert(!POOL || W >= 16, "pooled layers need whole-row tiles");
     static_assert(!UPS || W >= 16, "upsampled layers need whole-row tiles");
     static_assert(TILES % 2 == 0 && NPAIR % NMG == 0, "strip must split into tile pairs");
     static_assert(H % SR == 0 && SR % 2 == 0, "strip rows");
+    static_assert(MODE == STAGE_PF || MODE == STAGE_DB, "staging mode");
 };
 
 // Strip-local conv-grid coordinates of pixel `i` (0..15) of tile `t`.
@@ -83,11 +106,46 @@ __device__ __forceinline__ float relu_bn(float v, float bias, float s, float t)
 }
 
 template <class C>
+struct Stager {
+    using elem_t = typename std::conditional<C::CIN == 1, float, f32x4>::type;
+    // element `idx` of the strip of (cell, strip y0): loaded from `in`, zero in the halo
+    static __device__ __forceinline__ elem_t load(const float* __restrict__ in, long cell, int y0, int idx)
+    {
+        const int ybase = C::UPS ? (y0 / 2 - 1) : (y0 - 1);
+        const float* src = in + (size_t)cell * C::HS * C::WS * C::CIN;
+        const int pix = idx / C::C4, c4 = idx % C::C4;
+        const int r = pix / C::WP, c = pix % C::WP;
+        const int sy = ybase + r, sx = c - 1;
+        const bool ok = idx < C::TOT && sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS;
+        if constexpr (C::CIN == 1) {
+            return ok ? src[sy * C::WS + sx] : 0.0f;
+        } else {
+            elem_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ok) v = *(const f32x4*)(src + ((size_t)sy * C::WS + sx) * C::CIN + c4 * 4);
+            return v;
+        }
+    }
+    static __device__ __forceinline__ void store(char* strip, int idx, elem_t v)
+    {
+        if (idx < C::TOT) {
+            if constexpr (C::CIN == 1) {
+                *(float*)(strip + idx * 4) = v;
+            } else {
+                const int pix = idx / C::C4, c4 = idx % C::C4;
+                *(f32x4*)(strip + (pix * C::PS + c4 * 4) * 4) = v;
+            }
+        }
+    }
+};
+
+template <class C>
 __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wfrag, const float* __restrict__ ep,
     float* __restrict__ out, long n_cells)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using S = Stager<C>;
+    using elem_t = typename S::elem_t;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,43 +176,52 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     }
 
     const long total = n_cells * C::NSTRIP;
-    for (long item = blockIdx.x; item < total; item += gridDim.x) {
-        const long cell = item / C::NSTRIP;
-        const int strip = (int)(item % C::NSTRIP);
-        const int y0 = strip * C::SR;
+    const long first = blockIdx.x;
+    if (first >= total) return;
 
-        // ---- stage the strip (with zero halo) ------------------------------------
-        {
-            const int ybase = C::UPS ? (y0 / 2 - 1) : (y0 - 1);
-            const float* src = in + (size_t)cell * C::HS * C::WS * C::CIN;
-            if constexpr (C::CIN == 1) {
-                constexpr int TOT = C::R * C::WP;
-                for (int idx = tid; idx < TOT; idx += 256) {
-                    const int r = idx / C::WP, c = idx % C::WP;
-                    const int sy = ybase + r, sx = c - 1;
-                    float v = 0.0f;
-                    if (sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS) v = src[sy * C::WS + sx];
-                    *(float*)(smem + idx * 4) = v;
-                }
-            } else {
-                constexpr int C4 = C::CIN / 4;
-                constexpr int TOT = C::R * C::WP * C4;
+    // ---- prologue: first strip ---------------------------------------------------------
+    elem_t stg[C::MODE == STAGE_PF ? C::NLD : C::LPP];
+    if constexpr (C::MODE == STAGE_PF) {
+#pragma unroll
+        for (int k = 0; k < C::NLD; ++k)
+            stg[k] = S::load(in, first / C::NSTRIP, (int)(first % C::NSTRIP) * C::SR, tid + 256 * k);
+    } else {
 #pragma unroll 4
-                for (int idx = tid; idx < TOT; idx += 256) {
-                    const int pix = idx / C4, c4 = idx % C4;
-                    const int r = pix / C::WP, c = pix % C::WP;
-                    const int sy = ybase + r, sx = c - 1;
-                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS)
-                        v = *(const f32x4*)(src + ((size_t)sy * C::WS + sx) * C::CIN + c4 * 4);
-                    *(f32x4*)(smem + (pix * C::PS + c4 * 4) * 4) = v;
-                }
+        for (int idx = tid; idx < C::TOT; idx += 256)
+            S::store(smem, idx, S::load(in, first / C::NSTRIP, (int)(first % C::NSTRIP) * C::SR, idx));
+        __syncthreads();
+    }
+
+    int buf = 0;
+    for (long item = first; item < total; item += gridDim.x) {
+        const long cell = item / C::NSTRIP;
+        const int y0 = (int)(item % C::NSTRIP) * C::SR;
+        const long nitem = item + gridDim.x;
+        const bool has_next = nitem < total;
+        const long ncell = nitem / C::NSTRIP;
+        const int ny0 = (int)(nitem % C::NSTRIP) * C::SR;
+
+        if constexpr (C::MODE == STAGE_PF) {
+#pragma unroll
+            for (int k = 0; k < C::NLD; ++k) S::store(smem, tid + 256 * k, stg[k]);   // waits for the loads
+            __syncthreads();
+            if (has_next) {   // in flight during the MFMA loop
+#pragma unroll
+                for (int k = 0; k < C::NLD; ++k) stg[k] = S::load(in, ncell, ny0, tid + 256 * k);
             }
         }
-        __syncthreads();
+        const char* strip = smem + (C::MODE == STAGE_DB ? buf * C::STRIP_BYTES : 0);
+        char* nstrip = smem + (C::MODE == STAGE_DB ? (buf ^ 1) * C::STRIP_BYTES : 0);
 
         // ---- tile pairs ----------------------------------------------------------
-        for (int p = mg; p < C::NPAIR; p += C::NMG) {
+        int pi = 0;
+        for (int p = mg; p < C::NPAIR; p += C::NMG, ++pi) {
+            if constexpr (C::MODE == STAGE_DB) {
+                if (has_next) {   // this iteration's slice of the next strip: loads now, LDS writes at the bottom
+#pragma unroll
+                    for (int j = 0; j < C::LPP; ++j) stg[j] = S::load(in, ncell, ny0, tid + 256 * (pi * C::LPP + j));
+                }
+            }
             int t0, t1;
             if constexpr (C::POOL) {  // vertical pool partners: same columns, rows 2r and 2r+1
                 const int ry = 2 * (p / C::TPR), xb = p % C::TPR;
@@ -173,29 +240,45 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 const int b0 = (py0 * C::WP + px0) * 4, b1 = (py1 * C::WP + px1) * 4;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    float a0 = *(const float*)(smem + b0 + toff[s]);
-                    float a1 = *(const float*)(smem + b1 + toff[s]);
+                    float a0 = *(const float*)(strip + b0 + toff[s]);
+                    float a1 = *(const float*)(strip + b1 + toff[s]);
                     a0 = tval[s] ? a0 : 0.0f;
                     a1 = tval[s] ? a1 : 0.0f;
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
                 }
             } else {
+                // K walk in groups g = (tap, 16-channel block): one 16-B LDS read per tile feeds 4 MFMAs.
+                // The reads of group g+1 are issued before the MFMAs of group g (software prefetch),
+                // so the matrix pipe never waits on an LDS round trip.
+                constexpr int G = 9 * C::KQ;
+                int ad0[9], ad1[9];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int ad0 = a_addr<C>(py0, px0, kq, tap);
-                    const int ad1 = a_addr<C>(py1, px1, kq, tap);
+                    ad0[tap] = a_addr<C>(py0, px0, kq, tap);
+                    ad1[tap] = a_addr<C>(py1, px1, kq, tap);
+                }
+                f32x4 a0 = *(const f32x4*)(strip + ad0[0]);
+                f32x4 a1 = *(const f32x4*)(strip + ad1[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // group 0's reads
 #pragma unroll
-                    for (int q = 0; q < C::KQ; ++q) {
-                        const f32x4 a0 = *(const f32x4*)(smem + ad0 + q * 64);
-                        const f32x4 a1 = *(const f32x4*)(smem + ad1 + q * 64);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float b = B[(tap * C::KQ + q) * 4 + j];
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc1, 0, 0, 0);
-                        }
+                for (int g = 0; g < G; ++g) {
+                    f32x4 n0 = a0, n1 = a1;
+                    if (g + 1 < G) {
+                        n0 = *(const f32x4*)(strip + ad0[(g + 1) / C::KQ] + ((g + 1) % C::KQ) * 64);
+                        n1 = *(const f32x4*)(strip + ad1[(g + 1) / C::KQ] + ((g + 1) % C::KQ) * 64);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float b = B[g * 4 + j];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc1, 0, 0, 0);
+                    }
+                    a0 = n0;
+                    a1 = n1;
+                    // pin the schedule: this group's 2 prefetch reads first, then its 8 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 }
             }
 
@@ -227,34 +310,50 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                         relu_bn(acc1[r], bias, bns, bnt);
                 }
             }
+
+            if constexpr (C::MODE == STAGE_DB) {
+                if (has_next) {
+#pragma unroll
+                    for (int j = 0; j < C::LPP; ++j) S::store(nstrip, tid + 256 * (pi * C::LPP + j), stg[j]);
+                }
+            }
         }
-        __syncthreads();  // strip is re-staged by the next item
+        __syncthreads();  // all reads of this strip done; (STAGE_DB) next strip complete in the other buffer
+        buf ^= 1;
     }
 }
 
-//                      H   W  CIN COUT POOL   UPS   SR WPS
-using CfgL1 = ConvCfg<64, 64,  1, 32, true,  false, 16, 4>;   // CAE...:191-193
-using CfgL2 = ConvCfg<32, 32, 32, 64, true,  false,  8, 3>;   // :195-197
-using CfgL3 = ConvCfg<16, 16, 64, 32, true,  false,  8, 2>;   // :199-201 -> encoded 8x8x32
-using CfgL4 = ConvCfg< 8,  8, 32, 32, false, false,  8, 3>;   // :204-205
-using CfgL5 = ConvCfg<16, 16, 32, 64, false, true,  16, 3>;   // :206-209 (reads up(a4))
-using CfgL6 = ConvCfg<32, 32, 64, 32, false, true,   8, 2>;   // :210-213 (reads up(a5))
+//                      H   W  CIN COUT POOL   UPS   SR WPS MODE
+using CfgL1 = ConvCfg<64, 64,  1, 32, true,  false, 16, 4, STAGE_PF>;   // CAE...:191-193
+using CfgL2 = ConvCfg<32, 32, 32, 64, true,  false,  4, 3, STAGE_PF>;   // :195-197
+using CfgL3 = ConvCfg<16, 16, 64, 32, true,  false,  4, 2, STAGE_DB>;   // :199-201 -> encoded 8x8x32
+using CfgL4 = ConvCfg< 8,  8, 32, 32, false, false,  8, 3, STAGE_PF>;   // :204-205
+using CfgL5 = ConvCfg<16, 16, 32, 64, false, true,  16, 3, STAGE_PF>;   // :206-209 (reads up(a4))
+using CfgL6 = ConvCfg<32, 32, 64, 32, false, true,   8, 2, STAGE_DB>;   // :210-213 (reads up(a5))
 
 template <class C>
 static hipError_t launch_cfg(const float* in, const float* wfrag, const float* ep, float* out,
                              int64_t n_cells, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // Persistent grid = exactly the number of workgroups the chip holds at once (CUs x resident
+    // workgroups per CU for this kernel's registers and LDS): a larger grid would queue the
+    // surplus behind the first wave of workgroups and run it at a fraction of the occupancy.
+    static int resident = 0, cus = 0;
+    if (!resident) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<C>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int dev = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_mfma_kernel<C>, 256, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
     }
     const long total = (long)n_cells * C::NSTRIP;
     if (total <= 0) return hipSuccess;
-    const long max_blocks = 256L * 4;  // persistent: a few workgroups per CU
-    const unsigned grid = (unsigned)(total < max_blocks ? total : max_blocks);
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
     hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, in, wfrag, ep,
                        out, (long)n_cells);
     return hipGetLastError();

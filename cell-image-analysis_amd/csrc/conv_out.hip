@@ -4,10 +4,14 @@
 // The reconstruction itself is never written to HBM unless a debug pointer asks for it.
 //
 // cout = 1, so this is a per-pixel 288-term dot product, not a GEMM: a VALU kernel.
-// One thread owns one pixel of the stored (32x32) a6 grid = a 2x2 block of output pixels;
-// nearest upsampling means all 4 outputs read the same 3x3 neighbourhood of a6, so each
-// 16-B LDS read of 4 channels feeds up to 16 FMAs.  Weights arrive as a by-value kernel
-// argument, i.e. scalar loads from the kernarg segment into SGPRs.
+// One thread owns one pixel of the stored (32x32) a6 grid = a 2x2 block of output pixels.
+// Nearest upsampling makes the 3x3 taps of output (2y+a, 2x+b) fall on only 2x2 stored
+// pixels, rows y+a-1..y+a and columns x+b-1..x+b, several taps sharing one pixel; the taps
+// that share a pixel are pre-summed on the host into 16 effective weight vectors
+// W_eff[a][b][ry][rx][cin] (an exact algebraic identity; it changes only the order of fp32
+// roundings), so an output costs 4x32 FMAs instead of 9x32.  The zero padding of the
+// upsampled grid coincides with the zero halo of the stored grid.  Weights arrive as a
+// by-value kernel argument, i.e. scalar loads from the kernarg segment into SGPRs.
 #include "common.hpp"
 
 namespace cs {
@@ -20,7 +24,7 @@ constexpr int C7_R = C7_SR + 2, C7_WP = C7_WS + 2, C7_PS = C7_CIN + 4;
 constexpr int C7_LDS = C7_R * C7_WP * C7_PS * 4;
 constexpr int C7_NSTRIP = C7_HS / C7_SR;     // 4 partial sums per cell
 
-struct W7 { float w[9 * C7_CIN]; };          // [tap][cin]
+struct W7 { float w[16 * C7_CIN]; };         // W_eff[a][b][ry][rx][cin]
 
 __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
     const float* __restrict__ a6, const float* __restrict__ x, W7 wt, float b7,
@@ -63,20 +67,19 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
 #pragma unroll
                 for (int rx = 0; rx < 3; ++rx)
                     nb[ry][rx] = *(const f32x4*)(smem + (((ly + ry) * C7_WP + lx + rx) * C7_PS + q * 4) * 4);
-            // output (2y+a, 2x+b), tap (dy,dx) reads a6[y + ((a+dy)>>1)][x + ((b+dx)>>1)]
+            // output (2y+a, 2x+b) reads stored pixels (y+a-1+ry, x+b-1+rx), ry,rx in {0,1}
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
+                    for (int ry = 0; ry < 2; ++ry)
 #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int ny = ((a + dy) >> 1) + 1, nx = ((b + dx) >> 1) + 1;
-                            const int tap = (dy + 1) * 3 + (dx + 1);
+                        for (int rx = 0; rx < 2; ++rx) {
+                            const int e = ((a * 2 + b) * 2 + ry) * 2 + rx;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                acc[a][b] = fmaf(nb[ny][nx][j], wt.w[tap * C7_CIN + q * 4 + j], acc[a][b]);
+                                acc[a][b] = fmaf(nb[a + ry][b + rx][j], wt.w[e * C7_CIN + q * 4 + j], acc[a][b]);
                         }
         }
 
@@ -115,19 +118,37 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
 hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_host, float b7,
                             float* errpart, float* recon, int64_t n_cells, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int resident = 0;   // persistent grid = what the chip holds at once (see conv_mfma.hip)
+    if (!resident) {
         hipError_t e = hipFuncSetAttribute((const void*)conv7_err_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS + 32);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv7_err_kernel, 256, C7_LDS + 32);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
     }
     const long total = (long)n_cells * C7_NSTRIP;
     if (total <= 0) return hipSuccess;
+    // W_eff[a][b][ry][rx][ci] = sum of the taps (dy,dx) whose upsampled source pixel is stored
+    // pixel (y+a-1+ry, x+b-1+rx):  a=0: ry=0 <- dy=-1, ry=1 <- dy in {0,+1};  a=1: ry=0 <- dy in {-1,0}, ry=1 <- dy=+1.
     W7 wt;
-    for (int i = 0; i < 9 * C7_CIN; ++i) wt.w[i] = w7_host[i];  // HWIO with cout = 1 is [tap][cin]
-    const long max_blocks = 256L * 6;
-    const unsigned grid = (unsigned)(total < max_blocks ? total : max_blocks);
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int ry = 0; ry < 2; ++ry)
+                for (int rx = 0; rx < 2; ++rx)
+                    for (int ci = 0; ci < C7_CIN; ++ci) {
+                        float sum = 0.0f;
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx)
+                                if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx)
+                                    sum += w7_host[((dy + 1) * 3 + (dx + 1)) * C7_CIN + ci];  // HWIO, cout = 1
+                        wt.w[((((a * 2 + b) * 2 + ry) * 2 + rx)) * C7_CIN + ci] = sum;
+                    }
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
     hipLaunchKernelGGL(conv7_err_kernel, dim3(grid), dim3(256), C7_LDS + 32, stream, a6, x, wt, b7, errpart,
                        recon, (long)n_cells);
     return hipGetLastError();

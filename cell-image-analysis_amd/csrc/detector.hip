@@ -16,8 +16,9 @@ namespace {
 // A small exact-fp32 MFMA GEMM: 16 cells x cpad components per workgroup, K = features.
 // The scaler is fused into the staging of the A operand; the division is done in double
 // and rounded once, as numpy does for float32 /= float64.
-constexpr int PCA_CELLS = 16;
-constexpr int PCA_KC = 512;                       // features per LDS chunk
+constexpr int PCA_MT = 4;                         // 16-cell tiles per workgroup
+constexpr int PCA_CELLS = 16 * PCA_MT;
+constexpr int PCA_KC = 256;                       // features per LDS chunk
 constexpr int PCA_LD = PCA_KC + 4;                // padded row (floats)
 constexpr int PCA_LDS = PCA_CELLS * PCA_LD * 4;
 
@@ -32,11 +33,13 @@ __global__ __launch_bounds__(256) void scaler_pca_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const long cell0 = (long)blockIdx.x * PCA_CELLS;
-    const int ntiles = cpad / 16;
+    const int ntiles = cpad / 16;   // <= 8: wave w owns component tiles w and w + 4
 
-    f32x4 acc[4];
+    f32x4 acc[2][PCA_MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < PCA_MT; ++m) acc[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int k0 = 0; k0 < fpad; k0 += PCA_KC) {
         for (int idx = tid; idx < PCA_CELLS * PCA_KC; idx += 256) {
@@ -53,15 +56,20 @@ __global__ __launch_bounds__(256) void scaler_pca_kernel(
         __syncthreads();
 #pragma unroll 2
         for (int ks = 0; ks < PCA_KC / 16; ++ks) {
-            const f32x4 a = *(const f32x4*)(xs + li * PCA_LD + ks * 16 + kq * 4);
+            f32x4 a[PCA_MT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int m = 0; m < PCA_MT; ++m)
+                a[m] = *(const f32x4*)(xs + (m * 16 + li) * PCA_LD + ks * 16 + kq * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
                 const int tile = wave + 4 * t;  // wave-uniform
                 if (tile < ntiles) {
                     const f32x4 b = *(const f32x4*)(comps + (size_t)(tile * 16 + li) * fpad + k0 + ks * 16 + kq * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < PCA_MT; ++m)
+                            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[j], acc[t][m], 0, 0, 0);
                 }
             }
         }
@@ -69,23 +77,77 @@ __global__ __launch_bounds__(256) void scaler_pca_kernel(
     }
     // D[row = 4 kq + r (cell)][col = li (component)]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2; ++t) {
         const int comp = (wave + 4 * t) * 16 + li;
         if (wave + 4 * t < ntiles && comp < C) {
             const float mp = mean_proj[comp];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long cell = cell0 + 4 * kq + r;
-                if (cell < n) out[cell * C + comp] = acc[t][r] - mp;
-            }
+            for (int m = 0; m < PCA_MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long cell = cell0 + m * 16 + 4 * kq + r;
+                    if (cell < n) out[cell * C + comp] = acc[t][m][r] - mp;
+                }
         }
     }
 }
 
 // ---------------------------------------------------------------- one-class SVM decision
-// fp64 throughout (libsvm is double).  Lane <-> support vector, 16 cells per workgroup held
-// as doubles in LDS and read as wave-uniform broadcasts; each support-vector coordinate
-// loaded once serves 16 cells.  The sum over support vectors is reduced in a fixed order.
+// fp64 throughout (libsvm is double).  Lane <-> cell: a lane keeps its cell's D coordinates as
+// doubles in registers; support vectors are wave-uniform and arrive through scalar loads, so
+// the inner loop is two fp64 VALU instructions per (cell, sv, coordinate) and nothing else.
+// The eight waves of a workgroup share 64 cells and each walk an eighth of the support
+// vectors; their partial sums are added in wave order (deterministic).
+constexpr int SVMR_WAVES = 8;   // waves per workgroup = ways the support vectors are split
+
+template <int D>
+__global__ __launch_bounds__(64 * SVMR_WAVES, 2) void ocsvm_reg_kernel(
+    const float* __restrict__ pca, const double* __restrict__ sv /* [nsv_pad][D], zero padded */,
+    const double* __restrict__ coef /* [nsv_pad], zero padded */, int nsv, double gamma, double rho,
+    double* __restrict__ dec, long n)
+{
+    __shared__ double part[SVMR_WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long cell = (long)blockIdx.x * 64 + lane;
+    double x[D];
+    {
+        const long src = cell < n ? cell : n - 1;   // tail lanes recompute the last cell, never stored
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = (double)pca[src * D + d];
+    }
+    // support vectors are walked two at a time (rows 2j, 2j+1 of the zero-padded table: a padded
+    // row has coef 0), each distance split into two independent fma chains: four chains in
+    // flight hide the fp64 fma latency and let the two rows' scalar loads overlap.
+    const int npair = (nsv + 1) / 2;
+    const int per = (npair + SVMR_WAVES - 1) / SVMR_WAVES;
+    const int j0 = wave * per, j1 = (j0 + per < npair) ? j0 + per : npair;
+    double sum = 0.0;
+    for (int j = j0; j < j1; ++j) {
+        const double* __restrict__ s0 = sv + (size_t)(2 * j) * D;   // wave-uniform -> scalar loads
+        const double* __restrict__ s1 = s0 + D;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; d += 2) {
+            const double e0 = x[d] - s0[d], e1 = x[d + 1] - s0[d + 1];
+            const double f0 = x[d] - s1[d], f1 = x[d + 1] - s1[d + 1];
+            a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1);
+            b0 = fma(f0, f0, b0); b1 = fma(f1, f1, b1);
+        }
+        sum += coef[2 * j] * exp(-gamma * (a0 + a1));
+        sum += coef[2 * j + 1] * exp(-gamma * (b0 + b1));
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && cell < n) {
+        double t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < SVMR_WAVES; ++w) t += part[w][lane];
+        dec[cell] = t - rho;
+    }
+}
+
+// Generic-D fallback (D <= 128): lane <-> support vector, 16 cells per workgroup in LDS.
 constexpr int SVM_CELLS = 16;
 constexpr int SVM_MAXD = 128;
 
@@ -198,19 +260,30 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
                              int cpad, float* pca_out, int64_t n_cells, hipStream_t stream)
 {
     if (n_cells <= 0) return hipSuccess;
-    if (cpad % 16 || cpad > 256 || fpad % PCA_KC) return hipErrorInvalidValue;
+    if (cpad % 16 || cpad > 128 || fpad % PCA_KC) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_cells + PCA_CELLS - 1) / PCA_CELLS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)scaler_pca_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCA_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(scaler_pca_kernel, dim3(grid), dim3(256), PCA_LDS, stream, feat, center, scale,
                        comps_pad, mean_proj, F, fpad, C, cpad, pca_out, (long)n_cells);
     return hipGetLastError();
 }
 
-hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* coef, int nsv,
-                        int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
+hipError_t launch_ocsvm(const float* pca, int D, const double* sv, const double* svT, const double* coef,
+                        int nsv, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
                         hipStream_t stream)
 {
-    (void)nsv;
     if (n_cells <= 0) return hipSuccess;
+    if (D == 100) {   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
+        const unsigned grid = (unsigned)((n_cells + 63) / 64);
+        hipLaunchKernelGGL(ocsvm_reg_kernel<100>, dim3(grid), dim3(64 * SVMR_WAVES), 0, stream, pca, sv, coef, nsv, gamma, rho,
+                           dec, (long)n_cells);
+        return hipGetLastError();
+    }
     if (D > SVM_MAXD || nsv_pad % 256) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_cells + SVM_CELLS - 1) / SVM_CELLS);
     hipLaunchKernelGGL(ocsvm_kernel, dim3(grid), dim3(256), 0, stream, pca, D, svT, coef, nsv_pad, gamma,

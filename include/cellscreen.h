@@ -140,7 +140,7 @@ int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights
                          const cs_detector_params *detector, int device_id, cs_model **out);
 void cs_model_free(cs_model *m);
 int cs_model_get_info(const cs_model *m, cs_model_info *info);
-/* Cells per internal pass (workspace ~0.4 MB per cell).  Default 4096. */
+/* Cells per internal pass (workspace ~0.4 MB per cell).  Default 16384. */
 int cs_model_set_chunk(cs_model *m, int64_t chunk_cells);
 
 /* ---- the hot path -------------------------------------------------------------- */
