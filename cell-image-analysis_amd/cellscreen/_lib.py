@@ -42,6 +42,11 @@ class CSDetectorParams(C.Structure):
                 ("conservative", CSOcsvmParams), ("moderate", CSOcsvmParams)]
 
 
+class CSTrainCfg(C.Structure):
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+
+
 class CSModelInfo(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
                 ("feature_dim", C.c_int32), ("n_components", C.c_int32),
@@ -74,6 +79,17 @@ SIGNATURES = {
     "cs_profile_kernel_count": (_I, []),
     "cs_profile_kernel_name": (C.c_char_p, [_I]),
     "cs_profile_get": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_double)]),
+    "cs_train_param_count": (_I, [C.POINTER(_L), C.POINTER(_L)]),
+    "cs_train_create": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSTrainCfg), _I, C.POINTER(_P)]),
+    "cs_train_free": (None, [_P]),
+    "cs_train_step": (_I, [_P, _P, _P, _L, _I, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cs_train_forward_backward": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cs_train_apply": (_I, [_P, C.c_float]),
+    "cs_train_set_grad_buffer": (_I, [_P, _P]),
+    "cs_train_eval": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cs_train_export": (_I, [_P, _P, _P, _P]),
+    "cs_train_tensor": (_I, [_P, _I, _I, _L, _P]),
+    "cs_train_import": (_I, [_P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,163 @@
+"""Trainer: a Python handle on one cs_trainer (one GPU) -- the per-batch work of
+`autoencoder.fit` (CAE_improved_modeltrain.py:286-293).  All arithmetic runs in
+libcellscreen.so; this file only marshals buffers and splits the flat parameter vector."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from . import spec
+from .engine import _fill_cae
+from .spec import CAEWeights
+
+
+def param_layout(channels=spec.CHANNELS):
+    """[(name, shape)] of the flat trainable vector, Keras layer order."""
+    out = []
+    cin = 1
+    for l, cout in enumerate(channels):
+        out += [(f"conv{l}.kernel", (3, 3, cin, cout)), (f"conv{l}.bias", (cout,))]
+        if l < len(channels) - 1:
+            out += [(f"bn{l}.gamma", (cout,)), (f"bn{l}.beta", (cout,))]
+        cin = cout
+    return out
+
+
+def moving_layout(channels=spec.CHANNELS):
+    out = []
+    for l, cout in enumerate(channels[:-1]):
+        out += [(f"bn{l}.mean", (cout,)), (f"bn{l}.var", (cout,))]
+    return out
+
+
+def split_flat(flat: np.ndarray, layout):
+    out, o = {}, 0
+    for name, shape in layout:
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].reshape(shape).copy()
+        o += n
+    assert o == flat.size
+    return out
+
+
+def flat_from_weights(w: CAEWeights) -> Tuple[np.ndarray, np.ndarray]:
+    p, m = [], []
+    for l in range(w.n_conv):
+        p += [w.kernels[l].ravel(), w.biases[l].ravel()]
+        if l < w.n_conv - 1:
+            p += [w.bn_gamma[l], w.bn_beta[l]]
+            m += [w.bn_mean[l], w.bn_var[l]]
+    return np.concatenate(p).astype(np.float32), np.concatenate(m).astype(np.float32)
+
+
+def weights_from_flat(params: np.ndarray, moving: np.ndarray, bn_eps=spec.BN_EPS) -> CAEWeights:
+    p = split_flat(params, param_layout())
+    m = split_flat(moving, moving_layout())
+    n = len(spec.CHANNELS)
+    return CAEWeights([p[f"conv{l}.kernel"] for l in range(n)], [p[f"conv{l}.bias"] for l in range(n)],
+                      [p[f"bn{l}.gamma"] for l in range(n - 1)], [p[f"bn{l}.beta"] for l in range(n - 1)],
+                      [m[f"bn{l}.mean"] for l in range(n - 1)], [m[f"bn{l}.var"] for l in range(n - 1)],
+                      bn_eps=bn_eps).validate()
+
+
+class Trainer:
+    def __init__(self, init: CAEWeights, device_id: int = 0, beta1=spec.ADAM_B1, beta2=spec.ADAM_B2,
+                 adam_eps=spec.ADAM_EPS, bn_momentum=spec.BN_MOMENTUM):
+        self._lib = L.load_library()
+        keep: list = []
+        w = _fill_cae(init, keep)
+        cfg = L.CSTrainCfg(beta1, beta2, adam_eps, bn_momentum, init.bn_eps)
+        h = C.c_void_p()
+        L.check(self._lib.cs_train_create(C.byref(w), C.byref(cfg), device_id, C.byref(h)))
+        self._h = h
+        self.bn_eps = init.bn_eps
+        nt, nm = C.c_int64(), C.c_int64()
+        L.check(self._lib.cs_train_param_count(C.byref(nt), C.byref(nm)))
+        self.n_trainable, self.n_moving = nt.value, nm.value
+        self._grad_tensor = None
+
+    def close(self):
+        if self._h:
+            self._lib.cs_train_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _buf(a):
+        if isinstance(a, np.ndarray):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            return a, a.ctypes.data, L.CS_MEM_HOST, a.shape[0]
+        return a, a.data_ptr(), L.mem_kind(a), a.shape[0]
+
+    def step(self, x, y, lr: float = spec.ADAM_LR) -> Tuple[float, float]:
+        """forward + backward + Adam on one batch; returns (loss, mae) of the batch."""
+        xb, xp, kind, n = self._buf(x)
+        yb, yp, kind2, n2 = self._buf(y)
+        assert kind == kind2 and n == n2
+        loss, mae = C.c_float(), C.c_float()
+        L.check(self._lib.cs_train_step(self._h, xp, yp, n, kind, lr, C.byref(loss), C.byref(mae)))
+        return loss.value, mae.value
+
+    def forward_backward(self, x, y) -> Tuple[float, float]:
+        xb, xp, kind, n = self._buf(x)
+        yb, yp, kind2, n2 = self._buf(y)
+        assert kind == kind2 and n == n2
+        loss, mae = C.c_float(), C.c_float()
+        L.check(self._lib.cs_train_forward_backward(self._h, xp, yp, n, kind, C.byref(loss), C.byref(mae)))
+        return loss.value, mae.value
+
+    def apply(self, lr: float = spec.ADAM_LR):
+        L.check(self._lib.cs_train_apply(self._h, lr))
+
+    def use_grad_tensor(self, t):
+        """Gradients are written into this torch CUDA float32 tensor (n_trainable elements), so
+        torch.distributed can all-reduce it between forward_backward() and apply()."""
+        assert t.numel() == self.n_trainable and t.is_cuda and t.is_contiguous()
+        self._grad_tensor = t
+        L.check(self._lib.cs_train_set_grad_buffer(self._h, t.data_ptr()))
+
+    def evaluate(self, x, y) -> Tuple[float, float]:
+        xb, xp, kind, n = self._buf(x)
+        yb, yp, kind2, n2 = self._buf(y)
+        assert kind == kind2 and n == n2
+        loss, mae = C.c_float(), C.c_float()
+        L.check(self._lib.cs_train_eval(self._h, xp, yp, n, kind, C.byref(loss), C.byref(mae)))
+        return loss.value, mae.value
+
+    def tensor(self, which: int, layer: int, batch: int) -> np.ndarray:
+        """Stage tap (parity tests): which 0 relu out, 1 BN out, 2 dz, 3 dBN-out, 4 sigmoid out."""
+        rows = spec.layer_table()
+        if which == 4 or (which == 2 and layer == 6):
+            shape = (batch, 64, 64)
+        elif which in (0, 2):
+            shape = (batch,) + rows[layer]["conv_hw"] + (rows[layer]["cout"],)
+        else:
+            shape = (batch,) + rows[layer]["out_hw"] + (rows[layer]["cout"],)
+        out = np.empty(shape, np.float32)
+        L.check(self._lib.cs_train_tensor(self._h, which, layer, batch, out.ctypes.data))
+        return out
+
+    def export_flat(self, grads: bool = False):
+        p = np.empty(self.n_trainable, np.float32)
+        m = np.empty(self.n_moving, np.float32)
+        g = np.empty(self.n_trainable, np.float32) if grads else None
+        L.check(self._lib.cs_train_export(self._h, p.ctypes.data, m.ctypes.data, g.ctypes.data if grads else None))
+        return (p, m, g) if grads else (p, m)
+
+    def weights(self) -> CAEWeights:
+        p, m = self.export_flat()
+        return weights_from_flat(p, m, self.bn_eps)
+
+    def load_flat(self, params: Optional[np.ndarray], moving: Optional[np.ndarray]):
+        pp = np.ascontiguousarray(params, np.float32) if params is not None else None
+        mm = np.ascontiguousarray(moving, np.float32) if moving is not None else None
+        L.check(self._lib.cs_train_import(self._h, pp.ctypes.data if pp is not None else None,
+                                          mm.ctypes.data if mm is not None else None))

@@ -2,22 +2,16 @@
 // workspace, chunked orchestration of the kernels, measurement hooks.
 // There is deliberately no CPU path here: without a HIP device every compute entry
 // point fails with CS_ERR_NO_DEVICE.
-#include "../../include/cellscreen.h"
-#include "common.hpp"
+#include "api_internal.hpp"
 #include "tensor_archive.hpp"
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
 
 using namespace cs;
 
 // ---------------------------------------------------------------- errors
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...)
+namespace cs {
+int fail(int code, const char* fmt, ...)
 {
     char buf[1024];
     va_list ap;
@@ -27,43 +21,13 @@ static int fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
+const char* last_error_cstr() { return g_err.c_str(); }
+}  // namespace cs
 
-#define HIPCHK(expr)                                                                         \
-    do {                                                                                     \
-        hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
-            return fail(CS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
-                        __FILE__, __LINE__);                                                 \
-    } while (0)
-
-// ---------------------------------------------------------------- the reference graph
-static const int kRefChannels[7] = {32, 64, 32, 32, 64, 32, 1};
-static const int kNConv = 7, kNEnc = 3, kH = 64, kW = 64;
-// stored per-cell size (floats) of each conv's output tensor (after pool / before upsample)
-static const size_t kLayerFloats[7] = {32 * 32 * 32, 16 * 16 * 64, 8 * 8 * 32, 8 * 8 * 32,
-                                       16 * 16 * 64, 32 * 32 * 32, 64 * 64};
-// conv MACs per cell, SURVEY.md Appendix A.1
-static const double kLayerMacs[7] = {1179648, 18874368, 4718592, 589824, 4718592, 18874368, 1179648};
 static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool",
                                             "conv4_relu_bn",      "conv5_up_relu_bn",   "conv6_up_relu_bn",
                                             "conv7_up_sigmoid_err", "scaler_pca",       "ocsvm_decision",
                                             "finalize",           "synth_crops"};
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return CS_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        hipError_t e = hipMalloc(&p, need);
-        if (e != hipSuccess) { p = nullptr; return fail(CS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
-        bytes = need;
-        return CS_OK;
-    }
-    template <class T> T* as() const { return (T*)p; }
-};
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -78,8 +42,7 @@ struct cs_model {
     hipStream_t stream = nullptr;
     ConvSet ae, enc;
     bool shared_encoder = true;
-    float w7[9 * 32];
-    float b7 = 0.0f;
+    DevBuf w7eff, b7;      // conv7: effective weights [16][32] and bias, on device
     // detector
     bool has_det = false;
     int F = 0, fpad = 0, C = 0, cpad = 0;
@@ -103,7 +66,8 @@ struct cs_model {
 };
 
 // ---------------------------------------------------------------- small helpers
-static int upload(DevBuf& d, const void* src, size_t bytes)
+namespace cs {
+int upload(DevBuf& d, const void* src, size_t bytes)
 {
     int rc = d.ensure(bytes ? bytes : 16);
     if (rc) return rc;
@@ -111,7 +75,7 @@ static int upload(DevBuf& d, const void* src, size_t bytes)
     return CS_OK;
 }
 
-static int check_arch(const cs_cae_weights* w, int expect_convs, const char* what)
+int check_arch(const cs_cae_weights* w, int expect_convs, const char* what)
 {
     if (!w) return fail(CS_ERR_INVALID, "%s weights are NULL", what);
     if (w->height != kH || w->width != kW)
@@ -128,6 +92,21 @@ static int check_arch(const cs_cae_weights* w, int expect_convs, const char* wha
     }
     return CS_OK;
 }
+
+int require_gfx950(int device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CS_ERR_NO_DEVICE, "no HIP device visible; libcellscreen has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return fail(CS_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    return CS_OK;
+}
+}  // namespace cs
 
 // Pack convs [0, count) of a weight set.  BatchNormalization (inference) is reduced to
 // y = x*s + t with s = gamma / sqrt(var + eps), t = beta - mean*s, all in fp32.
@@ -273,7 +252,7 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     }
     if (last >= 6)
         LAUNCH(K_CONV7_ERR, nc,
-               launch_conv7_err(m->act[5].as<float>(), x, m->w7, m->b7, m->errpart.as<float>(), recon, nc, m->stream));
+               launch_conv7_err(m->act[5].as<float>(), x, m->w7eff.as<float>(), m->b7.as<float>(), m->errpart.as<float>(), recon, nc, m->stream));
     return CS_OK;
 }
 
@@ -345,7 +324,7 @@ const char* cs_status_string(int s)
     }
 }
 
-const char* cs_last_error(void) { return g_err.c_str(); }
+const char* cs_last_error(void) { return last_error_cstr(); }
 
 int cs_device_count(void)
 {
@@ -362,14 +341,7 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
     int rc = check_arch(autoencoder, kNConv, "autoencoder");
     if (rc) return rc;
     if (encoder && (rc = check_arch(encoder, kNEnc, "encoder"))) return rc;
-    const int ndev = cs_device_count();
-    if (ndev <= 0) return fail(CS_ERR_NO_DEVICE, "no HIP device visible; libcellscreen has no CPU path");
-    if (device_id < 0 || device_id >= ndev) return fail(CS_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, ndev);
-    HIPCHK(hipSetDevice(device_id));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device_id));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(CS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    if ((rc = require_gfx950(device_id))) return rc;
 
     cs_model* m = new (std::nothrow) cs_model();
     if (!m) return fail(CS_ERR_NOMEM, "host allocation failed");
@@ -380,8 +352,12 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
         if (e != hipSuccess) { delete m; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     }
     FAIL_IF(pack_set(m->ae, autoencoder, 6));
-    memcpy(m->w7, autoencoder->kernel[6], sizeof m->w7);
-    m->b7 = autoencoder->bias[6][0];
+    {
+        float weff[16 * 32];
+        conv7_effective_weights(autoencoder->kernel[6], weff);
+        FAIL_IF(upload(m->w7eff, weff, sizeof weff));
+        FAIL_IF(upload(m->b7, autoencoder->bias[6], sizeof(float)));
+    }
     m->shared_encoder = !encoder || same_encoder(autoencoder, encoder);
     if (!m->shared_encoder) FAIL_IF(pack_set(m->enc, encoder, kNEnc));
 

@@ -33,11 +33,40 @@ hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, cons
 size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);
 
 // conv7 + sigmoid + per-cell squared/absolute error partial sums.
-// a6: [n][32][32][32]; x: [n][64][64]; w7_host: HOST pointer, HWIO [3][3][32][1] (passed to
-// the kernel by value); errpart: [n][4][2];
-// recon (may be null): [n][64][64].
-hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_host, float b7,
+// a6: [n][32][32][32]; x: [n][64][64] (the array the reconstruction is compared with);
+// weff_dev: device, [16][32] effective weights (conv7_effective_weights / launch_pack_w7eff);
+// b7_dev: device, the conv's bias; errpart: [n][4][2]; recon (may be null): [n][64][64].
+hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,
                             float* errpart, float* recon, int64_t n_cells, hipStream_t stream);
+void conv7_effective_weights(const float* w7_hwio, float* weff);
+
+// ---- training (train.hip, conv_mfma.hip) -----------------------------------------------
+constexpr int TRAIN_MAX_PARTS = 256;   // workgroups (= partial sums) per reduction
+struct ReduceDesc { long dst; long len; const float* src; int nparts; long stride; };
+hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag, const float* bias,
+                                 float* relu_out, int64_t n_cells, hipStream_t stream);
+hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, float* dx, int64_t n_cells,
+                             hipStream_t stream);
+hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s);
+hipError_t launch_bn_apply(const float* r, const float* part, int G, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* mov_mean, float* mov_var, float* stats, float* a,
+                           long N, int H, int W, int pool, hipStream_t s);
+hipError_t launch_loss_dz(const float* out, const float* y, long total, float* dz, float* dzsum_part, int* G, hipStream_t s);
+hipError_t launch_loss_scalar(const float* errpart, long nparts, long nelem, float* out2, hipStream_t s);
+hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
+                                long N, int H, int W, int C, int pool, float* part, int* G, hipStream_t s);
+hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
+                            const float* part, int G, long N, int H, int W, int C, int pool, float* dz,
+                            float* dzsum_part, int* Gz, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
+                        hipStream_t s);
+hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
+                       hipStream_t s);
+hipError_t launch_pack_frag(const float* hwio, int cin, int cout, int transposed, float* dst, hipStream_t s);
+hipError_t launch_pack_w7eff(const float* w7, float* weff, hipStream_t s);
+hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* beta, const float* mov_mean,
+                          const float* mov_var, float eps, int C, float* ep, hipStream_t s);
 
 // scaler.transform + pca.transform.  comps_pad: [cpad][fpad], zero beyond [C][F];
 // cpad % 16 == 0, fpad % 512 == 0.

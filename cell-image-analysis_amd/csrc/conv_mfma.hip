@@ -36,10 +36,19 @@ namespace cs {
 // is why it uses STAGE_PF on 4-row strips rather than STAGE_DB.
 enum { STAGE_PF = 1, STAGE_DB = 2 };
 
-template <int H_, int W_, int CIN_, int COUT_, bool POOL_, bool UPS_, int SR_, int WPS_, int MODE_>
+// Epilogues:
+//   EPI_BN       bias -> ReLU -> BN(x*s+t)                      inference, decoder layers
+//   EPI_BN_POOL  bias -> ReLU -> BN -> 2x2 max-pool              inference, encoder layers
+//   EPI_RELU     bias -> ReLU (BatchNormalization in training mode needs batch statistics of
+//                this tensor first, so BN/pool run in their own kernels)   training forward
+//   EPI_PLAIN    nothing                                         training: gradient wrt the conv input
+//   EPI_SUMPOOL  2x2 sum (adjoint of UpSampling2D nearest)       training: same, through an upsample
+enum { EPI_BN = 0, EPI_BN_POOL = 1, EPI_RELU = 2, EPI_PLAIN = 3, EPI_SUMPOOL = 4 };
+
+template <int H_, int W_, int CIN_, int COUT_, int EPI_, bool UPS_, int SR_, int WPS_, int MODE_>
 struct ConvCfg {
-    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_, MODE = MODE_;
-    static constexpr bool POOL = POOL_, UPS = UPS_;
+    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_, MODE = MODE_, EPI = EPI_;
+    static constexpr bool POOL = (EPI_ == EPI_BN_POOL || EPI_ == EPI_SUMPOOL), UPS = UPS_;
     static constexpr int NSL = COUT / 16;            // 16-channel output slices (= waves along N)
     static constexpr int NMG = 4 / NSL;              // wave groups along M
     static constexpr int KQ = CIN / 16;              // 16-channel K blocks per tap (0 when CIN == 1)
@@ -68,6 +77,7 @@ struct ConvCfg {
     static_assert(TILES % 2 == 0 && NPAIR % NMG == 0, "strip must split into tile pairs");
     static_assert(H % SR == 0 && SR % 2 == 0, "strip rows");
     static_assert(MODE == STAGE_PF || MODE == STAGE_DB, "staging mode");
+    static_assert(LDS_BYTES <= 160 * 1024, "strip does not fit the 160 KB LDS");
 };
 
 // Strip-local conv-grid coordinates of pixel `i` (0..15) of tile `t`.
@@ -160,7 +170,9 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     for (int s = 0; s < C::NB; ++s) B[s] = wfrag[((size_t)nsl * C::NB + s) * 64 + lane];
 
     const int co = nsl * 16 + li;
-    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+    float bias = 0.0f, bns = 1.0f, bnt = 0.0f;
+    if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) { bias = ep[co]; bns = ep[C::COUT + co]; bnt = ep[2 * C::COUT + co]; }
+    if constexpr (C::EPI == EPI_RELU) bias = ep[co];
 
     // conv1: per-lane tap of each of the 3 K steps (k = 4 s + kq; k >= 9 is zero padding)
     int toff[3];
@@ -282,7 +294,12 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 }
             }
 
-            // ---- epilogue: D[row = 4*kq + r][col = li] -> bias, relu, BN, (pool), store
+            // ---- epilogue: D[row = 4*kq + r][col = li] -> per-mode transform, store
+            auto post = [&](float v) -> float {
+                if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) return relu_bn(v, bias, bns, bnt);
+                else if constexpr (C::EPI == EPI_RELU) return fmaxf(v + bias, 0.0f);
+                else return v;
+            };
             if constexpr (C::POOL) {
                 // lane holds pixels x = xq..xq+3 of rows (y, y+1); t0/t1 share columns
                 int qy, qx;
@@ -292,22 +309,25 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 float e0[4], e1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    e0[r] = relu_bn(acc0[r], bias, bns, bnt);
-                    e1[r] = relu_bn(acc1[r], bias, bns, bnt);
+                    e0[r] = post(acc0[r]);
+                    e1[r] = post(acc1[r]);
                 }
                 float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
-                o[0] = fmaxf(fmaxf(e0[0], e0[1]), fmaxf(e1[0], e1[1]));
-                o[C::COUT] = fmaxf(fmaxf(e0[2], e0[3]), fmaxf(e1[2], e1[3]));
+                if constexpr (C::EPI == EPI_SUMPOOL) {
+                    o[0] = (e0[0] + e0[1]) + (e1[0] + e1[1]);
+                    o[C::COUT] = (e0[2] + e0[3]) + (e1[2] + e1[3]);
+                } else {
+                    o[0] = fmaxf(fmaxf(e0[0], e0[1]), fmaxf(e1[0], e1[1]));
+                    o[C::COUT] = fmaxf(fmaxf(e0[2], e0[3]), fmaxf(e1[2], e1[3]));
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int qy, qx;
                     tile_pixel<C>(t0, 4 * kq + r, qy, qx);
-                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] =
-                        relu_bn(acc0[r], bias, bns, bnt);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = post(acc0[r]);
                     tile_pixel<C>(t1, 4 * kq + r, qy, qx);
-                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] =
-                        relu_bn(acc1[r], bias, bns, bnt);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = post(acc1[r]);
                 }
             }
 
@@ -323,13 +343,29 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     }
 }
 
-//                      H   W  CIN COUT POOL   UPS   SR WPS MODE
-using CfgL1 = ConvCfg<64, 64,  1, 32, true,  false, 16, 4, STAGE_PF>;   // CAE...:191-193
-using CfgL2 = ConvCfg<32, 32, 32, 64, true,  false,  4, 3, STAGE_PF>;   // :195-197
-using CfgL3 = ConvCfg<16, 16, 64, 32, true,  false,  4, 2, STAGE_DB>;   // :199-201 -> encoded 8x8x32
-using CfgL4 = ConvCfg< 8,  8, 32, 32, false, false,  8, 3, STAGE_PF>;   // :204-205
-using CfgL5 = ConvCfg<16, 16, 32, 64, false, true,  16, 3, STAGE_PF>;   // :206-209 (reads up(a4))
-using CfgL6 = ConvCfg<32, 32, 64, 32, false, true,   8, 2, STAGE_DB>;   // :210-213 (reads up(a5))
+//                       H   W  CIN COUT EPI          UPS    SR WPS MODE
+// inference (CAE_improved_modeltrain.py:191-214 with BatchNormalization in inference mode)
+using CfgL1 = ConvCfg<64, 64,  1, 32, EPI_BN_POOL, false, 16, 4, STAGE_PF>;   // :191-193
+using CfgL2 = ConvCfg<32, 32, 32, 64, EPI_BN_POOL, false,  4, 3, STAGE_PF>;   // :195-197
+using CfgL3 = ConvCfg<16, 16, 64, 32, EPI_BN_POOL, false,  4, 2, STAGE_DB>;   // :199-201 -> encoded 8x8x32
+using CfgL4 = ConvCfg< 8,  8, 32, 32, EPI_BN,      false,  8, 3, STAGE_PF>;   // :204-205
+using CfgL5 = ConvCfg<16, 16, 32, 64, EPI_BN,      true,  16, 3, STAGE_PF>;   // :206-209 (reads up(a4))
+using CfgL6 = ConvCfg<32, 32, 64, 32, EPI_BN,      true,   8, 2, STAGE_DB>;   // :210-213 (reads up(a5))
+// training forward: conv + bias + ReLU at full conv-grid resolution (BN batch stats come next)
+using CfgF1 = ConvCfg<64, 64,  1, 32, EPI_RELU,    false, 16, 4, STAGE_PF>;
+using CfgF2 = ConvCfg<32, 32, 32, 64, EPI_RELU,    false,  4, 3, STAGE_PF>;
+using CfgF3 = ConvCfg<16, 16, 64, 32, EPI_RELU,    false,  4, 2, STAGE_DB>;
+using CfgF4 = ConvCfg< 8,  8, 32, 32, EPI_RELU,    false,  8, 3, STAGE_PF>;
+using CfgF5 = ConvCfg<16, 16, 32, 64, EPI_RELU,    true,  16, 3, STAGE_PF>;
+using CfgF6 = ConvCfg<32, 32, 64, 32, EPI_RELU,    true,   8, 2, STAGE_DB>;
+// training backward-data: dX = conv(dZ, flipped/transposed kernel) [+ 2x2 sum through an upsample].
+// D<l> is the gradient wrt the input of conv l (1-based): channels swap roles.
+using CfgD7 = ConvCfg<64, 64,  1, 32, EPI_SUMPOOL, false, 16, 4, STAGE_PF>;   // dz7 (1 ch) -> d a6 (32x32x32)
+using CfgD6 = ConvCfg<32, 32, 32, 64, EPI_SUMPOOL, false,  4, 3, STAGE_PF>;   // dz6 (32 ch) -> d a5 (16x16x64)
+using CfgD5 = ConvCfg<16, 16, 64, 32, EPI_SUMPOOL, false,  4, 2, STAGE_DB>;   // dz5 (64 ch) -> d a4 (8x8x32)
+using CfgD4 = ConvCfg< 8,  8, 32, 32, EPI_PLAIN,   false,  8, 3, STAGE_PF>;   // dz4 -> d p3
+using CfgD3 = ConvCfg<16, 16, 32, 64, EPI_PLAIN,   false,  8, 3, STAGE_PF>;   // dz3 (32 ch) -> d p2 (16x16x64)
+using CfgD2 = ConvCfg<32, 32, 64, 32, EPI_PLAIN,   false,  4, 2, STAGE_DB>;   // dz2 (64 ch) -> d p1 (32x32x32)
 
 template <class C>
 static hipError_t launch_cfg(const float* in, const float* wfrag, const float* ep, float* out,
@@ -369,6 +405,34 @@ hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, cons
         case 3: return launch_cfg<CfgL4>(in, wfrag, ep, out, n_cells, stream);
         case 4: return launch_cfg<CfgL5>(in, wfrag, ep, out, n_cells, stream);
         case 5: return launch_cfg<CfgL6>(in, wfrag, ep, out, n_cells, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag, const float* bias,
+                                 float* relu_out, int64_t n_cells, hipStream_t stream)
+{
+    switch (layer) {
+        case 0: return launch_cfg<CfgF1>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 1: return launch_cfg<CfgF2>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 2: return launch_cfg<CfgF3>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 3: return launch_cfg<CfgF4>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 4: return launch_cfg<CfgF5>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 5: return launch_cfg<CfgF6>(in, wfrag, bias, relu_out, n_cells, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, float* dx,
+                             int64_t n_cells, hipStream_t stream)
+{
+    switch (layer) {   // 0-based conv index whose INPUT gradient is produced (layer 0 has none)
+        case 1: return launch_cfg<CfgD2>(dz, wfrag_t, nullptr, dx, n_cells, stream);
+        case 2: return launch_cfg<CfgD3>(dz, wfrag_t, nullptr, dx, n_cells, stream);
+        case 3: return launch_cfg<CfgD4>(dz, wfrag_t, nullptr, dx, n_cells, stream);
+        case 4: return launch_cfg<CfgD5>(dz, wfrag_t, nullptr, dx, n_cells, stream);
+        case 5: return launch_cfg<CfgD6>(dz, wfrag_t, nullptr, dx, n_cells, stream);
+        case 6: return launch_cfg<CfgD7>(dz, wfrag_t, nullptr, dx, n_cells, stream);
         default: return hipErrorInvalidValue;
     }
 }

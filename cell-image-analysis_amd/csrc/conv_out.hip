@@ -10,8 +10,8 @@
 // that share a pixel are pre-summed on the host into 16 effective weight vectors
 // W_eff[a][b][ry][rx][cin] (an exact algebraic identity; it changes only the order of fp32
 // roundings), so an output costs 4x32 FMAs instead of 9x32.  The zero padding of the
-// upsampled grid coincides with the zero halo of the stored grid.  Weights arrive as a
-// by-value kernel argument, i.e. scalar loads from the kernarg segment into SGPRs.
+// upsampled grid coincides with the zero halo of the stored grid.  The weight indices are
+// wave-uniform, so W_eff is fetched with scalar loads into SGPRs.
 #include "common.hpp"
 
 namespace cs {
@@ -24,12 +24,12 @@ constexpr int C7_R = C7_SR + 2, C7_WP = C7_WS + 2, C7_PS = C7_CIN + 4;
 constexpr int C7_LDS = C7_R * C7_WP * C7_PS * 4;
 constexpr int C7_NSTRIP = C7_HS / C7_SR;     // 4 partial sums per cell
 
-struct W7 { float w[16 * C7_CIN]; };         // W_eff[a][b][ry][rx][cin]
 
 __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
-    const float* __restrict__ a6, const float* __restrict__ x, W7 wt, float b7,
-    float* __restrict__ errpart, float* __restrict__ recon, long n_cells)
+    const float* __restrict__ a6, const float* __restrict__ x, const float* __restrict__ weff /*[16][32]*/,
+    const float* __restrict__ b7p, float* __restrict__ errpart, float* __restrict__ recon, long n_cells)
 {
+    const float b7 = b7p[0];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float (*red)[4] = (float (*)[4])(smem + C7_LDS);  // 2 x 4 wave sums, after the strip
     const int tid = threadIdx.x;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
                             const int e = ((a * 2 + b) * 2 + ry) * 2 + rx;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                acc[a][b] = fmaf(nb[a + ry][b + rx][j], wt.w[e * C7_CIN + q * 4 + j], acc[a][b]);
+                                acc[a][b] = fmaf(nb[a + ry][b + rx][j], weff[e * C7_CIN + q * 4 + j], acc[a][b]);
                         }
         }
 
@@ -115,7 +115,25 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
 }
 }  // namespace
 
-hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_host, float b7,
+// W_eff[a][b][ry][rx][ci] = sum of the taps (dy,dx) whose upsampled source pixel is stored
+// pixel (y+a-1+ry, x+b-1+rx):  a=0: ry=0 <- dy=-1, ry=1 <- dy in {0,+1};  a=1: ry=0 <- dy in {-1,0}, ry=1 <- dy=+1.
+void conv7_effective_weights(const float* w7_hwio, float* weff /*[16][32]*/)
+{
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int ry = 0; ry < 2; ++ry)
+                for (int rx = 0; rx < 2; ++rx)
+                    for (int ci = 0; ci < C7_CIN; ++ci) {
+                        float sum = 0.0f;
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx)
+                                if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx)
+                                    sum += w7_hwio[((dy + 1) * 3 + (dx + 1)) * C7_CIN + ci];  // HWIO, cout = 1
+                        weff[((((a * 2 + b) * 2 + ry) * 2 + rx)) * C7_CIN + ci] = sum;
+                    }
+}
+
+hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,
                             float* errpart, float* recon, int64_t n_cells, hipStream_t stream)
 {
     static int resident = 0;   // persistent grid = what the chip holds at once (see conv_mfma.hip)
@@ -133,23 +151,8 @@ hipError_t launch_conv7_err(const float* a6, const float* x, const float* w7_hos
     }
     const long total = (long)n_cells * C7_NSTRIP;
     if (total <= 0) return hipSuccess;
-    // W_eff[a][b][ry][rx][ci] = sum of the taps (dy,dx) whose upsampled source pixel is stored
-    // pixel (y+a-1+ry, x+b-1+rx):  a=0: ry=0 <- dy=-1, ry=1 <- dy in {0,+1};  a=1: ry=0 <- dy in {-1,0}, ry=1 <- dy=+1.
-    W7 wt;
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
-            for (int ry = 0; ry < 2; ++ry)
-                for (int rx = 0; rx < 2; ++rx)
-                    for (int ci = 0; ci < C7_CIN; ++ci) {
-                        float sum = 0.0f;
-                        for (int dy = -1; dy <= 1; ++dy)
-                            for (int dx = -1; dx <= 1; ++dx)
-                                if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx)
-                                    sum += w7_host[((dy + 1) * 3 + (dx + 1)) * C7_CIN + ci];  // HWIO, cout = 1
-                        wt.w[((((a * 2 + b) * 2 + ry) * 2 + rx)) * C7_CIN + ci] = sum;
-                    }
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv7_err_kernel, dim3(grid), dim3(256), C7_LDS + 32, stream, a6, x, wt, b7, errpart,
+    hipLaunchKernelGGL(conv7_err_kernel, dim3(grid), dim3(256), C7_LDS + 32, stream, a6, x, weff_dev, b7_dev, errpart,
                        recon, (long)n_cells);
     return hipGetLastError();
 }

@@ -1,0 +1,689 @@
+// train.hip -- kernels of one `autoencoder.fit` step (CAE_improved_modeltrain.py:223-227, 286-293)
+// that are not convolutions over the forward template: BatchNormalization in training mode
+// (batch statistics, moving-average update, backward), max-pool routing, MSE loss gradient,
+// weight gradients (MFMA GEMM over pixels), partial-sum reduction, Adam, fragment re-packing.
+// Reductions over the batch are two-level and summed in a fixed order: results are
+// deterministic run to run (no float atomics anywhere).
+#include "common.hpp"
+
+namespace cs {
+
+namespace {
+
+// ============================================================== BatchNormalization, forward
+// r: [P][C] relu output (P = batch*H*W pixels).  Each workgroup reduces a contiguous pixel range
+// to {count, mean, M2} per channel (two passes over its range: exact local mean first), the
+// consumers merge the G partials with Chan's formula in double.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ r, long P, int C,
+                                                               float* __restrict__ part /*[G][3][C]*/)
+{
+    __shared__ float red[256];
+    __shared__ float meanc[64];
+    const int tid = threadIdx.x;
+    const int c = tid % C, lane = tid / C, L = 256 / C;
+    const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+    float s = 0.0f;
+    for (long p = p0 + lane; p < p1; p += L) s += r[p * C + c];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.0f;
+        for (int l = 0; l < L; ++l) t += red[l * C + tid];
+        meanc[tid] = t / (float)(p1 - p0);
+    }
+    __syncthreads();
+    const float mu = meanc[c];
+    float m2 = 0.0f;
+    for (long p = p0 + lane; p < p1; p += L) { const float d = r[p * C + c] - mu; m2 = fmaf(d, d, m2); }
+    __syncthreads();
+    red[tid] = m2;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.0f;
+        for (int l = 0; l < L; ++l) t += red[l * C + tid];
+        float* o = part + (size_t)blockIdx.x * 3 * C;
+        o[tid] = (float)(p1 - p0);
+        o[C + tid] = meanc[tid];
+        o[2 * C + tid] = t;
+    }
+}
+
+__device__ __forceinline__ void bn_merge(const float* __restrict__ part, int G, int C, int c,
+                                         double& mean, double& var)
+{
+    double n = 0.0, mu = 0.0, M2 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const float* o = part + (size_t)g * 3 * C;
+        const double nb = o[c], mb = o[C + c], M2b = o[2 * C + c];
+        const double tot = n + nb, delta = mb - mu;
+        mu += delta * (nb / tot);
+        M2 += M2b + delta * delta * (n * nb / tot);
+        n = tot;
+    }
+    mean = mu;
+    var = M2 / n;   // biased, as Keras normalises with (and Keras 3 averages) the batch variance
+}
+
+// y = gamma*(r-mean)*inv + beta, then 2x2 max-pool (encoder) or identity (decoder).
+// Block 0 also publishes {mean, inv} for the backward pass and updates the moving statistics
+// (moving = moving*momentum + batch*(1-momentum)).
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const float* __restrict__ r, const float* __restrict__ part, int G, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ mov_mean, float* __restrict__ mov_var, float* __restrict__ stats /*[2][C]*/,
+    float* __restrict__ a, long N, int H, int W, int pool)
+{
+    __shared__ float sm[64], si[64], sg[64], sb[64];
+    const int tid = threadIdx.x;
+    if (tid < C) {
+        double mean, var;
+        bn_merge(part, G, C, tid, mean, var);
+        const float fm = (float)mean, fv = (float)var;
+        const float inv = 1.0f / sqrtf(fv + eps);
+        sm[tid] = fm; si[tid] = inv; sg[tid] = gamma[tid]; sb[tid] = beta[tid];
+        if (blockIdx.x == 0) {
+            stats[tid] = fm;
+            stats[C + tid] = inv;
+            mov_mean[tid] = mov_mean[tid] * momentum + fm * (1.0f - momentum);
+            mov_var[tid] = mov_var[tid] * momentum + fv * (1.0f - momentum);
+        }
+    }
+    __syncthreads();
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    const long total = N * Ho * Wo * C;
+    for (long o = (long)blockIdx.x * 256 + tid; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const long pix = o / C;
+        const float g = sg[c] * si[c], b = sb[c] - sm[c] * g;   // y = r*g + b
+        if (pool) {
+            const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho);
+            const long n = pix / ((long)Wo * Ho);
+            const float* p = r + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+            const float y00 = fmaf(p[0], g, b), y01 = fmaf(p[C], g, b);
+            const float y10 = fmaf(p[(long)W * C], g, b), y11 = fmaf(p[(long)W * C + C], g, b);
+            a[o] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+        } else {
+            a[o] = fmaf(r[o], g, b);
+        }
+    }
+}
+
+// ============================================================== loss
+// dz7 = dL/dz of the sigmoid conv: L = mean((out-y)^2) over all B*H*W elements (loss='mse').
+__global__ __launch_bounds__(256) void loss_dz_kernel(const float* __restrict__ out, const float* __restrict__ y,
+                                                      long total, float* __restrict__ dz,
+                                                      float* __restrict__ dzsum_part /*[G]*/)
+{
+    __shared__ float red[4];
+    const float k = 2.0f / (float)total;
+    float s = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float o = out[i];
+        const float d = k * (o - y[i]) * o * (1.0f - o);
+        dz[i] = d;
+        s += d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dzsum_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// loss / mae scalars from the conv7 error partial sums (errpart: [B][4][2]).
+__global__ void loss_scalar_kernel(const float* __restrict__ errpart, long nparts, long nelem, float* __restrict__ out2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s2 = 0.0, s1 = 0.0;
+    for (long i = 0; i < nparts; ++i) { s2 += errpart[2 * i]; s1 += errpart[2 * i + 1]; }
+    out2[0] = (float)(s2 / (double)nelem);
+    out2[1] = (float)(s1 / (double)nelem);
+}
+
+// ============================================================== BatchNormalization, backward
+// Gradient arriving at the BN output: `da` at pooled resolution for encoder layers (MaxPooling2D
+// routes it to the arg-max of each 2x2 window of y = BN(r), first maximum in (dy,dx) order),
+// at full resolution for decoder layers.
+struct Win { float dy[4]; float xh[4]; float r[4]; };
+
+__device__ __forceinline__ void window(const float* __restrict__ da, const float* __restrict__ r, long n, int yo,
+                                       int xo, int c, int H, int W, int C, float mean, float inv, float gam,
+                                       float bet, Win& w)
+{
+    const float* p = r + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+    w.r[0] = p[0]; w.r[1] = p[C]; w.r[2] = p[(long)W * C]; w.r[3] = p[(long)W * C + C];
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w.xh[j] = (w.r[j] - mean) * inv;
+        const float y = fmaf(w.xh[j], gam, bet);
+        if (y > best) { best = y; arg = j; }
+    }
+    const float g = da[((n * (H / 2) + yo) * (W / 2) + xo) * C + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.dy[j] = (j == arg) ? g : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ da, const float* __restrict__ r, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, long N, int H, int W, int C, int pool,
+    float* __restrict__ part /*[G][2][C]*/)
+{
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const int c = tid % C, lane = tid / C, L = 256 / C;
+    const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
+    double s0 = 0.0, s1 = 0.0;
+    if (pool) {
+        const long P = N * (H / 2) * (W / 2);
+        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+        for (long p = p0 + lane; p < p1; p += L) {
+            const int xo = (int)(p % (W / 2)), yo = (int)((p / (W / 2)) % (H / 2));
+            const long n = p / ((long)(W / 2) * (H / 2));
+            Win w;
+            window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0 += w.dy[j]; s1 += (double)w.dy[j] * w.xh[j]; }
+        }
+    } else {
+        const long P = N * H * W;
+        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+        for (long p = p0 + lane; p < p1; p += L) {
+            const float dy = da[p * C + c];
+            const float xh = (r[p * C + c] - mean) * inv;
+            s0 += dy;
+            s1 += (double)dy * xh;
+        }
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
+    __syncthreads();
+    if (tid < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int l = 0; l < L; ++l) { t0 += red[0][l * C + tid]; t1 += red[1][l * C + tid]; }
+        part[(size_t)blockIdx.x * 2 * C + tid] = (float)t0;
+        part[(size_t)blockIdx.x * 2 * C + C + tid] = (float)t1;
+    }
+}
+
+// dz = relu'(r) * gamma*inv * (dy - mean(dy) - xhat*mean(dy*xhat)); also sum(dz) per channel
+// (the conv bias gradient) and, from block 0, dgamma = sum(dy*xhat), dbeta = sum(dy).
+__global__ __launch_bounds__(256) void bn_bwd_dz_kernel(
+    const float* __restrict__ da, const float* __restrict__ r, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, int G,
+    long N, int H, int W, int C, int pool, float* __restrict__ dz, float* __restrict__ dzsum_part /*[Gz][C]*/,
+    float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ float sdy[64], sdx[64];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (tid < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int g = 0; g < G; ++g) { t0 += part[(size_t)g * 2 * C + tid]; t1 += part[(size_t)g * 2 * C + C + tid]; }
+        const double nred = (double)N * H * W;
+        sdy[tid] = (float)(t0 / nred);
+        sdx[tid] = (float)(t1 / nred);
+        if (blockIdx.x == 0) { dbeta[tid] = (float)t0; dgamma[tid] = (float)t1; }
+    }
+    __syncthreads();
+    const int c = tid % C, lane = tid / C, L = 256 / C;
+    const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
+    const float k = gam * inv, mdy = sdy[c], mdx = sdx[c];
+    double s = 0.0;
+    if (pool) {
+        const long P = N * (H / 2) * (W / 2);
+        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+        for (long p = p0 + lane; p < p1; p += L) {
+            const int xo = (int)(p % (W / 2)), yo = (int)((p / (W / 2)) % (H / 2));
+            const long n = p / ((long)(W / 2) * (H / 2));
+            Win w;
+            window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
+            float* o = dz + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+            const long offs[4] = {0, C, (long)W * C, (long)W * C + C};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dr = k * (w.dy[j] - mdy - w.xh[j] * mdx);
+                const float v = w.r[j] > 0.0f ? dr : 0.0f;
+                o[offs[j]] = v;
+                s += v;
+            }
+        }
+    } else {
+        const long P = N * H * W;
+        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+        for (long p = p0 + lane; p < p1; p += L) {
+            const float rv = r[p * C + c];
+            const float xh = (rv - mean) * inv;
+            const float dr = k * (da[p * C + c] - mdy - xh * mdx);
+            const float v = rv > 0.0f ? dr : 0.0f;
+            dz[p * C + c] = v;
+            s += v;
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        double t = 0.0;
+        for (int l = 0; l < L; ++l) t += red[l * C + tid];
+        dzsum_part[(size_t)blockIdx.x * C + tid] = (float)t;
+    }
+}
+
+// ============================================================== weight gradients
+// dW[tap][ci][co] = sum over (cell, y, x) X[y+dy][x+dx][ci] * dZ[y][x][co]   (X zero padded, and
+// read through >>1 when an UpSampling2D precedes the conv): an exact-fp32 MFMA GEMM with
+// M = (tap, ci), N = co, K = pixels.  A workgroup stages an input strip and the matching dZ
+// strip in LDS, every wave owns the M tiles {w, w+4, ...} x all N tiles and keeps their
+// accumulators in registers across all the items of its persistent loop; partial sums go to
+// part[workgroup][M][N] and are reduced in workgroup order by reduce_all_kernel.
+template <int H_, int W_, int CIN_, int COUT_, bool UPS_, int SR_>
+struct WgCfg {
+    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_;
+    static constexpr bool UPS = UPS_;
+    static constexpr int HS = UPS ? H / 2 : H, WS = UPS ? W / 2 : W;
+    static constexpr int R = UPS ? SR / 2 + 2 : SR + 2, WP = WS + 2;
+    static constexpr int PS = CIN + 16, DZP = COUT + 16;           // padded pixel strides (floats)
+    static constexpr int XS_BYTES = R * WP * PS * 4, DZ_BYTES = SR * W * DZP * 4;
+    static constexpr int LDS_BYTES = XS_BYTES + DZ_BYTES;
+    static constexpr int KQ = CIN / 16, MT = 9 * KQ, NT = COUT / 16, MTW = (MT + 3) / 4;
+    static constexpr int NSTRIP = H / SR;
+    static constexpr int M = 9 * CIN;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(W % 4 == 0 && CIN % 16 == 0 && COUT % 16 == 0 && H % SR == 0 && SR % 2 == 0, "shape");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict__ xin, const float* __restrict__ dz,
+                                                         float* __restrict__ part, long n_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;
+    float* dzs = (float*)(smem + C::XS_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[C::MTW][C::NT];
+#pragma unroll
+    for (int mi = 0; mi < C::MTW; ++mi)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) acc[mi][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const long total = n_cells * C::NSTRIP;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long cell = item / C::NSTRIP;
+        const int y0 = (int)(item % C::NSTRIP) * C::SR;
+        // stage the input strip (zero halo) and the dZ strip
+        {
+            constexpr int C4 = C::CIN / 4, TOT = C::R * C::WP * C4;
+            const int ybase = C::UPS ? (y0 / 2 - 1) : (y0 - 1);
+            const float* src = xin + (size_t)cell * C::HS * C::WS * C::CIN;
+#pragma unroll 4
+            for (int idx = tid; idx < TOT; idx += 256) {
+                const int pix = idx / C4, c4 = idx % C4;
+                const int r = pix / C::WP, c = pix % C::WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS)
+                    v = *(const f32x4*)(src + ((size_t)sy * C::WS + sx) * C::CIN + c4 * 4);
+                *(f32x4*)(xs + pix * C::PS + c4 * 4) = v;
+            }
+            constexpr int D4 = C::COUT / 4, DTOT = C::SR * C::W * D4;
+            const float* dsrc = dz + ((size_t)cell * C::H + y0) * C::W * C::COUT;
+#pragma unroll 4
+            for (int idx = tid; idx < DTOT; idx += 256) {
+                const int pix = idx / D4, c4 = idx % D4;
+                *(f32x4*)(dzs + pix * C::DZP + c4 * 4) = *(const f32x4*)(dsrc + (size_t)pix * C::COUT + c4 * 4);
+            }
+        }
+        __syncthreads();
+        for (int y = 0; y < C::SR; ++y)
+            for (int xq = 0; xq < C::W / 4; ++xq) {
+                const int x = 4 * xq + kq;   // this lane's pixel of the 4-pixel K step
+                float b[C::NT];
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt) b[nt] = dzs[(y * C::W + x) * C::DZP + 16 * nt + li];
+#pragma unroll
+                for (int mi = 0; mi < C::MTW; ++mi) {
+                    const int mt = wave + 4 * mi;   // wave-uniform
+                    if (mt < C::MT) {
+                        const int tap = mt / C::KQ, cb = mt % C::KQ;
+                        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                        int pr, pc;
+                        if constexpr (C::UPS) { pr = ((y + dy) >> 1) + 1; pc = ((x + dx) >> 1) + 1; }
+                        else { pr = y + dy + 1; pc = x + dx + 1; }
+                        const float a = xs[(pr * C::WP + pc) * C::PS + 16 * cb + li];
+#pragma unroll
+                        for (int nt = 0; nt < C::NT; ++nt)
+                            acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mi][nt], 0, 0, 0);
+                    }
+                }
+            }
+        __syncthreads();
+    }
+    // D[row = 4 kq + r -> m][col = li -> n]
+    float* o = part + (size_t)blockIdx.x * C::M * C::COUT;
+#pragma unroll
+    for (int mi = 0; mi < C::MTW; ++mi) {
+        const int mt = wave + 4 * mi;
+        if (mt < C::MT) {
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o[(size_t)(mt * 16 + 4 * kq + r) * C::COUT + nt * 16 + li] = acc[mi][nt][r];
+        }
+    }
+}
+
+//                    H   W  CIN COUT UPS    SR
+using WgL2 = WgCfg<32, 32, 32, 64, false,  8>;
+using WgL3 = WgCfg<16, 16, 64, 32, false,  8>;
+using WgL4 = WgCfg< 8,  8, 32, 32, false,  8>;
+using WgL5 = WgCfg<16, 16, 32, 64, true,  16>;
+using WgL6 = WgCfg<32, 32, 64, 32, true,   8>;
+
+template <class C>
+hipError_t launch_wg(const float* xin, const float* dz, float* part, int64_t n_cells, int max_parts, int* nparts,
+                     hipStream_t stream)
+{
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_mfma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const long total = (long)n_cells * C::NSTRIP;
+    const int grid = (int)(total < max_parts ? total : max_parts);
+    *nparts = grid;
+    hipLaunchKernelGGL(wgrad_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, xin, dz, part, (long)n_cells);
+    return hipGetLastError();
+}
+
+// conv1 (cin = 1): dW[tap][co] = sum x[y+dy][x+dx] * dz[y][x][co].  Thread = (co, pixel lane).
+__global__ __launch_bounds__(256) void wgrad_first_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                          float* __restrict__ part /*[G][9][32]*/, long n_cells)
+{
+    constexpr int H = 64, W = 64, CO = 32, SR = 16, WP = W + 2, R = SR + 2;
+    __shared__ float xs[R * WP];
+    __shared__ float red[256];
+    const int tid = threadIdx.x, co = tid & 31, lane = tid >> 5;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+    const long total = n_cells * (H / SR);
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long cell = item / (H / SR);
+        const int y0 = (int)(item % (H / SR)) * SR;
+        for (int idx = tid; idx < R * WP; idx += 256) {
+            const int r = idx / WP, c = idx % WP;
+            const int sy = y0 - 1 + r, sx = c - 1;
+            xs[idx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(cell * H + sy) * W + sx] : 0.0f;
+        }
+        __syncthreads();
+        for (int p = lane; p < SR * W; p += 8) {
+            const int y = p / W, xx = p % W;
+            const float d = dz[((cell * H + y0 + y) * W + xx) * CO + co];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = fmaf(xs[(y + t / 3) * WP + xx + t % 3], d, acc[t]);
+        }
+        __syncthreads();
+    }
+    for (int t = 0; t < 9; ++t) {
+        red[tid] = acc[t];
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.0f;
+            for (int l = 0; l < 8; ++l) s += red[l * 32 + tid];
+            part[((size_t)blockIdx.x * 9 + t) * CO + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// conv7 (cout = 1, reads up(a6)): dW[tap][ci] = sum a6[(Y+dy)>>1][(X+dx)>>1][ci] * dz7[Y][X].
+__global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict__ a6, const float* __restrict__ dz7,
+                                                         float* __restrict__ part /*[G][9][32]*/, long n_cells)
+{
+    constexpr int HS = 32, WS = 32, CI = 32, SRS = 8, WP = WS + 2, R = SRS + 2, PS = CI + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* as = (float*)smem;                 // [R][WP][PS]
+    float* red = as + R * WP * PS;            // [256]
+    const int tid = threadIdx.x, ci = tid & 31, lane = tid >> 5;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+    const long total = n_cells * (HS / SRS);
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long cell = item / (HS / SRS);
+        const int ys0 = (int)(item % (HS / SRS)) * SRS;   // first stored row
+        for (int idx = tid; idx < R * WP * CI; idx += 256) {
+            const int c = idx % CI, pix = idx / CI;
+            const int r = pix / WP, cc = pix % WP;
+            const int sy = ys0 - 1 + r, sx = cc - 1;
+            as[pix * PS + c] = (sy >= 0 && sy < HS && sx >= 0 && sx < WS) ? a6[((cell * HS + sy) * WS + sx) * CI + c] : 0.0f;
+        }
+        __syncthreads();
+        const int Y0 = 2 * ys0;
+        for (int p = lane; p < 2 * SRS * 64; p += 8) {
+            const int Yl = p / 64, X = p % 64;      // output pixel (Y0 + Yl, X)
+            const float d = dz7[(cell * 64 + Y0 + Yl) * 64 + X];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const int pr = ((Yl + dy) >> 1) + 1, pc = ((X + dx) >> 1) + 1;
+                acc[t] = fmaf(as[(pr * WP + pc) * PS + ci], d, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = 0; t < 9; ++t) {
+        red[tid] = acc[t];
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.0f;
+            for (int l = 0; l < 8; ++l) s += red[l * 32 + tid];
+            part[((size_t)blockIdx.x * 9 + t) * CI + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ============================================================== reduce / Adam / packing
+__global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long base = 0;
+    for (int d = 0; d < ndesc; ++d) {
+        const ReduceDesc& D = descs[d];
+        if (i < base + D.len) {
+            const long e = i - base;
+            float s = 0.0f;
+            for (int p = 0; p < D.nparts; ++p) s += D.src[(size_t)p * D.stride + e];
+            flat_grad[D.dst + e] = s;
+            return;
+        }
+        base += D.len;
+    }
+}
+
+// Keras Adam: w -= alpha * m / (sqrt(v) + eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float alpha, float b1, float b2, float eps)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    p[i] -= (mi * alpha) / (sqrtf(vi) + eps);
+}
+
+// B-operand fragments of conv_mfma_kernel from an HWIO kernel in device memory.
+// transposed = 1 builds the backward-data kernel: W'[tap][ci'][co'] = W[8-tap][co'][ci'].
+__global__ void pack_frag_kernel(const float* __restrict__ hwio, int cin, int cout, int transposed,
+                                 float* __restrict__ dst)
+{
+    const int ecin = transposed ? cout : cin, ecout = transposed ? cin : cout;   // effective conv shape
+    const int kq_n = ecin / 16, nb = (ecin == 1) ? 3 : 9 * kq_n * 4;
+    const int total = (ecout / 16) * nb * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63, s = (i >> 6) % nb, nsl = (i >> 6) / nb;
+    const int li = lane & 15, kq = lane >> 4, co = nsl * 16 + li;
+    int tap, ci;
+    bool valid = true;
+    if (ecin == 1) { tap = 4 * s + kq; ci = 0; valid = tap < 9; }
+    else { const int j = s & 3, q = (s >> 2) % kq_n; tap = (s >> 2) / kq_n; ci = 16 * q + 4 * kq + j; }
+    float v = 0.0f;
+    if (valid) v = transposed ? hwio[((size_t)(8 - tap) * cin + co) * cout + ci] : hwio[((size_t)tap * cin + ci) * cout + co];
+    dst[i] = v;
+}
+
+// W_eff[a][b][ry][rx][ci] of conv7_err_kernel from the HWIO (3,3,32,1) kernel in device memory.
+__global__ void pack_w7eff_kernel(const float* __restrict__ w7, float* __restrict__ weff)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 16 * 32) return;
+    const int ci = i & 31, e = i >> 5;
+    const int rx = e & 1, ry = (e >> 1) & 1, b = (e >> 2) & 1, a = (e >> 3) & 1;
+    float sum = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+            if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx) sum += w7[((dy + 1) * 3 + (dx + 1)) * 32 + ci];
+    weff[i] = sum;
+}
+
+// {bias, s, t} epilogue constants of the inference kernels from trainable params + moving stats.
+__global__ void pack_ep_kernel(const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mov_mean, const float* __restrict__ mov_var, float eps, int C,
+                               float* __restrict__ ep)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(mov_var[c] + eps);
+    ep[c] = bias[c];
+    ep[C + c] = s;
+    ep[2 * C + c] = beta[c] - mov_mean[c] * s;
+}
+
+}  // namespace
+
+// ============================================================== launchers
+static int stat_grid(long P) { long g = P / 512; if (g < 1) g = 1; if (g > TRAIN_MAX_PARTS) g = TRAIN_MAX_PARTS; return (int)g; }
+
+hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s)
+{
+    if (256 % C) return hipErrorInvalidValue;
+    *G = stat_grid(P);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(*G), dim3(256), 0, s, r, P, C, part);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_apply(const float* r, const float* part, int G, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* mov_mean, float* mov_var, float* stats, float* a,
+                           long N, int H, int W, int pool, hipStream_t s)
+{
+    const long total = N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
+    long g = (total + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, r, part, G, C, gamma, beta, eps, momentum,
+                       mov_mean, mov_var, stats, a, N, H, W, pool);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_dz(const float* out, const float* y, long total, float* dz, float* dzsum_part, int* G, hipStream_t s)
+{
+    long g = (total + 4095) / 4096; if (g < 1) g = 1; if (g > TRAIN_MAX_PARTS) g = TRAIN_MAX_PARTS;
+    *G = (int)g;
+    hipLaunchKernelGGL(loss_dz_kernel, dim3(*G), dim3(256), 0, s, out, y, total, dz, dzsum_part);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_scalar(const float* errpart, long nparts, long nelem, float* out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(loss_scalar_kernel, dim3(1), dim3(64), 0, s, errpart, nparts, nelem, out2);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
+                                long N, int H, int W, int C, int pool, float* part, int* G, hipStream_t s)
+{
+    *G = stat_grid(N * (pool ? H / 2 : H) * (pool ? W / 2 : W));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(*G), dim3(256), 0, s, da, r, stats, gamma, beta, N, H, W, C, pool, part);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
+                            const float* part, int G, long N, int H, int W, int C, int pool, float* dz,
+                            float* dzsum_part, int* Gz, float* dgamma, float* dbeta, hipStream_t s)
+{
+    *Gz = stat_grid(N * (pool ? H / 2 : H) * (pool ? W / 2 : W));
+    hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(*Gz), dim3(256), 0, s, da, r, stats, gamma, beta, part, G, N, H, W, C, pool, dz,
+                       dzsum_part, dgamma, dbeta);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
+                        hipStream_t s)
+{
+    const int mp = TRAIN_MAX_PARTS;
+    switch (layer) {
+        case 0: {
+            const long total = n_cells * 4;
+            *nparts = (int)(total < mp ? total : mp);
+            hipLaunchKernelGGL(wgrad_first_kernel, dim3(*nparts), dim3(256), 0, s, xin, dz, part, (long)n_cells);
+            return hipGetLastError();
+        }
+        case 1: return launch_wg<WgL2>(xin, dz, part, n_cells, mp, nparts, s);
+        case 2: return launch_wg<WgL3>(xin, dz, part, n_cells, mp, nparts, s);
+        case 3: return launch_wg<WgL4>(xin, dz, part, n_cells, mp, nparts, s);
+        case 4: return launch_wg<WgL5>(xin, dz, part, n_cells, mp, nparts, s);
+        case 5: return launch_wg<WgL6>(xin, dz, part, n_cells, mp, nparts, s);
+        case 6: {
+            const long total = n_cells * 4;
+            *nparts = (int)(total < mp ? total : mp);
+            const int lds = (10 * 34 * 33 + 256) * 4;
+            hipLaunchKernelGGL(wgrad_last_kernel, dim3(*nparts), dim3(256), lds, s, xin, dz, part, (long)n_cells);
+            return hipGetLastError();
+        }
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((total_len + 255) / 256)), dim3(256), 0, s, descs_dev, ndesc, flat_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, alpha, b1, b2, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_frag(const float* hwio, int cin, int cout, int transposed, float* dst, hipStream_t s)
+{
+    const int ecin = transposed ? cout : cin, ecout = transposed ? cin : cout;
+    const int nb = (ecin == 1) ? 3 : 9 * (ecin / 16) * 4;
+    const int total = (ecout / 16) * nb * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hwio, cin, cout, transposed, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_w7eff(const float* w7, float* weff, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_w7eff_kernel, dim3(2), dim3(256), 0, s, w7, weff);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* beta, const float* mov_mean,
+                          const float* mov_var, float eps, int C, float* ep, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_ep_kernel, dim3(1), dim3(64), 0, s, bias, gamma, beta, mov_mean, mov_var, eps, C, ep);
+    return hipGetLastError();
+}
+
+}  // namespace cs

@@ -1,0 +1,352 @@
+// train_api.hip -- C ABI of the CAE trainer (include/cellscreen.h, cs_train_*): one
+// `autoencoder.fit` step of CAE_improved_modeltrain.py:286-293 on the graph compiled at
+// :223-227 -- forward with BatchNormalization in training mode, MSE loss / MAE metric,
+// backward, Keras Adam -- plus the inference-mode evaluation used for val_loss.
+// Callbacks (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, :263-283) are host-side
+// scalars and live in cellscreen/training.py.
+#include "api_internal.hpp"
+
+#include <cmath>
+
+using namespace cs;
+
+struct cs_trainer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cs_train_cfg cfg;
+    int64_t maxb = 0;
+    // flat parameter layout, Keras order: conv l kernel (HWIO), bias, [gamma, beta]
+    long off_k[7], off_b[7], off_g[6], off_be[6], nparam = 0;
+    long off_mm[6], off_mv[6], nmov = 0;
+    DevBuf P, Gown, M, V, MOV;
+    float* G = nullptr;                 // gradient buffer in use (own or caller's)
+    long step = 0;
+    // packed operands, rebuilt after every update
+    DevBuf wf[6], wft[7], w7eff, ep_inf[6];
+    // batch tensors
+    DevBuf x, y, r[6], a[6], out, errpart, dz[7], da[6], stats[6];
+    DevBuf part_stats, part_bwd, dzsum_part[7], wpart[7], descs, scal;
+    int np_w[7], np_b[7];
+    ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+static int cin_of(int l) { return l == 0 ? 1 : kRefChannels[l - 1]; }
+static size_t a_floats(int l) { return kLayerFloats[l]; }                                   // stored BN output per cell
+static size_t r_floats(int l) { return (size_t)kConvGrid[l] * kConvGrid[l] * kRefChannels[l]; }  // conv-grid tensor per cell
+
+#define LCHK(call)                                                                             \
+    do {                                                                                       \
+        hipError_t le__ = (call);                                                              \
+        if (le__ != hipSuccess) return fail(CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(le__)); \
+    } while (0)
+
+static int repack(cs_trainer* t)
+{
+    float* P = t->P.as<float>();
+    for (int l = 0; l < 6; ++l)
+        LCHK(launch_pack_frag(P + t->off_k[l], cin_of(l), kRefChannels[l], 0, t->wf[l].as<float>(), t->stream));
+    for (int l = 1; l < 7; ++l)
+        LCHK(launch_pack_frag(P + t->off_k[l], cin_of(l), kRefChannels[l], 1, t->wft[l].as<float>(), t->stream));
+    LCHK(launch_pack_w7eff(P + t->off_k[6], t->w7eff.as<float>(), t->stream));
+    return CS_OK;
+}
+
+static int ensure_batch(cs_trainer* t, int64_t b)
+{
+    if (b <= t->maxb) return CS_OK;
+    int rc;
+    if ((rc = t->x.ensure((size_t)b * kH * kW * 4)) || (rc = t->y.ensure((size_t)b * kH * kW * 4))) return rc;
+    for (int l = 0; l < 6; ++l) {
+        if ((rc = t->r[l].ensure(b * r_floats(l) * 4)) || (rc = t->a[l].ensure(b * a_floats(l) * 4)) ||
+            (rc = t->da[l].ensure(b * a_floats(l) * 4)) || (rc = t->dz[l].ensure(b * r_floats(l) * 4)))
+            return rc;
+    }
+    if ((rc = t->dz[6].ensure((size_t)b * kH * kW * 4)) || (rc = t->out.ensure((size_t)b * kH * kW * 4)) ||
+        (rc = t->errpart.ensure((size_t)b * 8 * 4)))
+        return rc;
+    t->maxb = b;
+    return CS_OK;
+}
+
+extern "C" {
+
+int cs_train_param_count(int64_t* n_trainable, int64_t* n_moving)
+{
+    long n = 0, m = 0;
+    for (int l = 0; l < 7; ++l) {
+        n += 9L * cin_of(l) * kRefChannels[l] + kRefChannels[l];
+        if (l < 6) { n += 2L * kRefChannels[l]; m += 2L * kRefChannels[l]; }
+    }
+    if (n_trainable) *n_trainable = n;
+    if (n_moving) *n_moving = m;
+    return CS_OK;
+}
+
+int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int device_id, cs_trainer** out)
+{
+    if (!out) return fail(CS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!cfg) return fail(CS_ERR_INVALID, "cfg is NULL");
+    int rc = check_arch(init, kNConv, "initial weights");
+    if (rc) return rc;
+    if ((rc = require_gfx950(device_id))) return rc;
+    cs_trainer* t = new (std::nothrow) cs_trainer();
+    if (!t) return fail(CS_ERR_NOMEM, "host allocation failed");
+    t->device = device_id;
+    t->cfg = *cfg;
+#define TFAIL(x) do { int r__ = (x); if (r__) { delete t; return r__; } } while (0)
+    {
+        hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete t; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    }
+    long o = 0, mo = 0;
+    for (int l = 0; l < 7; ++l) {
+        t->off_k[l] = o; o += 9L * cin_of(l) * kRefChannels[l];
+        t->off_b[l] = o; o += kRefChannels[l];
+        if (l < 6) {
+            t->off_g[l] = o; o += kRefChannels[l];
+            t->off_be[l] = o; o += kRefChannels[l];
+            t->off_mm[l] = mo; mo += kRefChannels[l];
+            t->off_mv[l] = mo; mo += kRefChannels[l];
+        }
+    }
+    t->nparam = o; t->nmov = mo;
+    std::vector<float> hp(o), hm(mo);
+    for (int l = 0; l < 7; ++l) {
+        const int c = kRefChannels[l];
+        memcpy(&hp[t->off_k[l]], init->kernel[l], sizeof(float) * 9 * cin_of(l) * c);
+        memcpy(&hp[t->off_b[l]], init->bias[l], sizeof(float) * c);
+        if (l < 6) {
+            memcpy(&hp[t->off_g[l]], init->bn_gamma[l], sizeof(float) * c);
+            memcpy(&hp[t->off_be[l]], init->bn_beta[l], sizeof(float) * c);
+            memcpy(&hm[t->off_mm[l]], init->bn_mean[l], sizeof(float) * c);
+            memcpy(&hm[t->off_mv[l]], init->bn_var[l], sizeof(float) * c);
+        }
+    }
+    TFAIL(upload(t->P, hp.data(), o * 4));
+    TFAIL(upload(t->MOV, hm.data(), mo * 4));
+    TFAIL(t->Gown.ensure(o * 4)); TFAIL(t->M.ensure(o * 4)); TFAIL(t->V.ensure(o * 4));
+    t->G = t->Gown.as<float>();
+    {
+        hipError_t e1 = hipMemset(t->M.p, 0, o * 4), e2 = hipMemset(t->V.p, 0, o * 4), e3 = hipMemset(t->Gown.p, 0, o * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { delete t; return fail(CS_ERR_HIP, "hipMemset failed"); }
+    }
+    for (int l = 0; l < 6; ++l) {
+        TFAIL(t->wf[l].ensure(pack_conv_fragments(cin_of(l), kRefChannels[l], nullptr, nullptr) * 4));
+        TFAIL(t->ep_inf[l].ensure(3 * kRefChannels[l] * 4));
+        TFAIL(t->stats[l].ensure(2 * kRefChannels[l] * 4));
+    }
+    for (int l = 1; l < 7; ++l)   // backward-data fragments: effective conv (cin' = cout, cout' = cin)
+        TFAIL(t->wft[l].ensure(pack_conv_fragments(kRefChannels[l], cin_of(l), nullptr, nullptr) * 4));
+    TFAIL(t->w7eff.ensure(16 * 32 * 4));
+    TFAIL(t->part_stats.ensure((size_t)TRAIN_MAX_PARTS * 3 * 64 * 4));
+    TFAIL(t->part_bwd.ensure((size_t)TRAIN_MAX_PARTS * 2 * 64 * 4));
+    for (int l = 0; l < 7; ++l) {
+        TFAIL(t->dzsum_part[l].ensure((size_t)TRAIN_MAX_PARTS * 64 * 4));
+        TFAIL(t->wpart[l].ensure((size_t)TRAIN_MAX_PARTS * 9 * cin_of(l) * kRefChannels[l] * 4));
+    }
+    TFAIL(t->descs.ensure(14 * sizeof(ReduceDesc)));
+    TFAIL(t->scal.ensure(16));
+    TFAIL(repack(t));
+    {
+        hipError_t e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) { delete t; return fail(CS_ERR_HIP, "initial repack: %s", hipGetErrorString(e)); }
+    }
+#undef TFAIL
+    *out = t;
+    return CS_OK;
+}
+
+void cs_train_free(cs_trainer* t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    delete t;
+}
+
+int cs_train_set_grad_buffer(cs_trainer* t, float* device_buffer)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    t->G = device_buffer ? device_buffer : t->Gown.as<float>();
+    return CS_OK;
+}
+
+static int copy_in(cs_trainer* t, DevBuf& dst, const float* src, int kind, size_t floats)
+{
+    HIPCHK(hipMemcpyAsync(dst.p, src, floats * 4, kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, t->stream));
+    return CS_OK;
+}
+
+int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (!x || !y || batch <= 0) return fail(CS_ERR_INVALID, "x/y NULL or batch <= 0");
+    if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
+    HIPCHK(hipSetDevice(t->device));
+    int rc = ensure_batch(t, batch);
+    if (rc) return rc;
+    const int64_t B = batch;
+    hipStream_t s = t->stream;
+    float* P = t->P.as<float>();
+    float* G = t->G;
+    float* MOV = t->MOV.as<float>();
+    if ((rc = copy_in(t, t->x, x, kind, (size_t)B * kH * kW)) || (rc = copy_in(t, t->y, y, kind, (size_t)B * kH * kW))) return rc;
+
+    // ---- forward, BatchNormalization in training mode ---------------------------------
+    for (int l = 0; l < 6; ++l) {
+        const int C = kRefChannels[l], Hc = kConvGrid[l], pool = l < kNEnc;
+        const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+        LCHK(launch_conv_train_fwd(l, in, t->wf[l].as<float>(), P + t->off_b[l], t->r[l].as<float>(), B, s));
+        int G1 = 0;
+        LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * Hc * Hc, C, t->part_stats.as<float>(), &G1, s));
+        LCHK(launch_bn_apply(t->r[l].as<float>(), t->part_stats.as<float>(), G1, C, P + t->off_g[l], P + t->off_be[l],
+                             t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l], MOV + t->off_mv[l],
+                             t->stats[l].as<float>(), t->a[l].as<float>(), B, Hc, Hc, pool, s));
+    }
+    LCHK(launch_conv7_err(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6],
+                          t->errpart.as<float>(), t->out.as<float>(), B, s));
+    LCHK(launch_loss_scalar(t->errpart.as<float>(), B * 4, B * kH * kW, t->scal.as<float>(), s));
+
+    // ---- backward -------------------------------------------------------------------------
+    LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * kH * kW, t->dz[6].as<float>(),
+                        t->dzsum_part[6].as<float>(), &t->np_b[6], s));
+    LCHK(launch_wgrad(6, t->a[5].as<float>(), t->dz[6].as<float>(), t->wpart[6].as<float>(), B, &t->np_w[6], s));
+    LCHK(launch_conv_dgrad(6, t->dz[6].as<float>(), t->wft[6].as<float>(), t->da[5].as<float>(), B, s));
+    for (int l = 5; l >= 0; --l) {
+        const int C = kRefChannels[l], Hc = kConvGrid[l], pool = l < kNEnc;
+        int G2 = 0;
+        LCHK(launch_bn_bwd_reduce(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
+                                  P + t->off_be[l], B, Hc, Hc, C, pool, t->part_bwd.as<float>(), &G2, s));
+        LCHK(launch_bn_bwd_dz(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
+                              P + t->off_be[l], t->part_bwd.as<float>(), G2, B, Hc, Hc, C, pool, t->dz[l].as<float>(),
+                              t->dzsum_part[l].as<float>(), &t->np_b[l], G + t->off_g[l], G + t->off_be[l], s));
+        const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+        LCHK(launch_wgrad(l, in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, &t->np_w[l], s));
+        if (l > 0) LCHK(launch_conv_dgrad(l, t->dz[l].as<float>(), t->wft[l].as<float>(), t->da[l - 1].as<float>(), B, s));
+    }
+    // ---- all partial sums -> flat gradient, in workgroup order -----------------------------
+    ReduceDesc d[14];
+    long total = 0;
+    for (int l = 0; l < 7; ++l) {
+        const long klen = 9L * cin_of(l) * kRefChannels[l];
+        d[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
+        d[2 * l + 1] = ReduceDesc{t->off_b[l], (long)kRefChannels[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)kRefChannels[l]};
+        total += klen + kRefChannels[l];
+    }
+    HIPCHK(hipMemcpyAsync(t->descs.p, d, sizeof d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // `d` is a stack array: the copy must finish before it dies
+    LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 14, total, G, s));
+    float h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, t->scal.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (loss) *loss = h[0];
+    if (mae) *mae = h[1];
+    return CS_OK;
+}
+
+int cs_train_apply(cs_trainer* t, float lr)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    t->step += 1;
+    const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
+    const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+    LCHK(launch_adam(t->P.as<float>(), t->G, t->M.as<float>(), t->V.as<float>(), t->nparam, alpha, t->cfg.beta1,
+                     t->cfg.beta2, t->cfg.adam_eps, t->stream));
+    int rc = repack(t);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return CS_OK;
+}
+
+int cs_train_step(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float lr, float* loss, float* mae)
+{
+    int rc = cs_train_forward_backward(t, x, y, batch, kind, loss, mae);
+    if (rc) return rc;
+    return cs_train_apply(t, lr);
+}
+
+int cs_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (!x || !y || n <= 0) return fail(CS_ERR_INVALID, "x/y NULL or n <= 0");
+    if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
+    HIPCHK(hipSetDevice(t->device));
+    const int64_t ch = n < 4096 ? n : 4096;
+    int rc = ensure_batch(t, ch);
+    if (rc) return rc;
+    hipStream_t s = t->stream;
+    float* P = t->P.as<float>();
+    float* MOV = t->MOV.as<float>();
+    for (int l = 0; l < 6; ++l)
+        LCHK(launch_pack_ep(P + t->off_b[l], P + t->off_g[l], P + t->off_be[l], MOV + t->off_mm[l], MOV + t->off_mv[l],
+                            t->cfg.bn_eps, kRefChannels[l], t->ep_inf[l].as<float>(), s));
+    double s2 = 0.0, s1 = 0.0;
+    std::vector<float> part;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        if ((rc = copy_in(t, t->x, x + (size_t)off * kH * kW, kind, (size_t)nc * kH * kW)) ||
+            (rc = copy_in(t, t->y, y + (size_t)off * kH * kW, kind, (size_t)nc * kH * kW)))
+            return rc;
+        for (int l = 0; l < 6; ++l) {
+            const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+            LCHK(launch_conv_mfma(l, in, t->wf[l].as<float>(), t->ep_inf[l].as<float>(), t->a[l].as<float>(), nc, s));
+        }
+        LCHK(launch_conv7_err(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6],
+                              t->errpart.as<float>(), nullptr, nc, s));
+        part.resize((size_t)nc * 8);
+        HIPCHK(hipMemcpyAsync(part.data(), t->errpart.p, part.size() * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < part.size(); i += 2) { s2 += part[i]; s1 += part[i + 1]; }
+    }
+    if (loss) *loss = (float)(s2 / ((double)n * kH * kW));
+    if (mae) *mae = (float)(s1 / ((double)n * kH * kW));
+    return CS_OK;
+}
+
+int cs_train_export(cs_trainer* t, float* params_host, float* moving_host, float* grads_host)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (params_host) HIPCHK(hipMemcpy(params_host, t->P.p, t->nparam * 4, hipMemcpyDeviceToHost));
+    if (moving_host) HIPCHK(hipMemcpy(moving_host, t->MOV.p, t->nmov * 4, hipMemcpyDeviceToHost));
+    if (grads_host) HIPCHK(hipMemcpy(grads_host, t->G, t->nparam * 4, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_train_tensor(cs_trainer* t, int which, int layer, int64_t batch, float* host)
+{
+    if (!t || !host) return fail(CS_ERR_INVALID, "NULL argument");
+    if (layer < 0 || layer > 6 || batch <= 0 || batch > t->maxb) return fail(CS_ERR_INVALID, "bad layer/batch");
+    HIPCHK(hipSetDevice(t->device));
+    const DevBuf* b = nullptr;
+    size_t per = 0;
+    switch (which) {
+        case 0: if (layer < 6) { b = &t->r[layer]; per = r_floats(layer); } break;    // relu(conv) output
+        case 1: if (layer < 6) { b = &t->a[layer]; per = a_floats(layer); } break;    // BN (+pool) output
+        case 2: b = &t->dz[layer]; per = layer < 6 ? r_floats(layer) : (size_t)kH * kW; break;   // dL/dz
+        case 3: if (layer < 6) { b = &t->da[layer]; per = a_floats(layer); } break;   // dL/d(BN output)
+        case 4: b = &t->out; per = (size_t)kH * kW; break;                             // sigmoid output
+        default: break;
+    }
+    if (!b) return fail(CS_ERR_INVALID, "no such tensor");
+    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(hipMemcpy(host, b->p, (size_t)batch * per * 4, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_train_import(cs_trainer* t, const float* params_host, const float* moving_host)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    if (params_host) HIPCHK(hipMemcpy(t->P.p, params_host, t->nparam * 4, hipMemcpyHostToDevice));
+    if (moving_host) HIPCHK(hipMemcpy(t->MOV.p, moving_host, t->nmov * 4, hipMemcpyHostToDevice));
+    int rc = repack(t);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return CS_OK;
+}
+
+}  // extern "C"

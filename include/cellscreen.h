@@ -21,6 +21,10 @@
  *        stage-level taps used by the parity tests (oracle inputs to each stage)
  *   cs_synth_crops
  *        synthetic U[0,1) crops (no reference counterpart; benchmark/test input)
+ *   cs_train_create / cs_train_step / cs_train_eval / cs_train_export
+ *        the per-batch work of autoencoder.fit       CAE_improved_modeltrain.py:286-293
+ *        on the model compiled at :223-227 (Adam 1e-3, loss 'mse', metric 'mae'); the
+ *        callbacks of :263-283 are host-side scalars (cellscreen/training.py)
  *
  * Conventions
  *   - Every function returns CS_OK (0) or a negative cs_status.  cs_last_error()
@@ -193,6 +197,46 @@ const char *cs_profile_kernel_name(int kernel_id);
  * flops: algorithmic FLOPs of those launches (2 x MACs of the reference graph). */
 int cs_profile_get(cs_model *m, int kernel_id, double *total_ms, int64_t *launches,
                    int64_t *cells, double *flops);
+
+/* ---- training ---------------------------------------------------------------------- */
+typedef struct cs_trainer cs_trainer;
+
+/* Keras defaults of the reference: Adam(beta_1 0.9, beta_2 0.999, epsilon 1e-7)
+ * (CAE_improved_modeltrain.py:224), BatchNormalization(momentum 0.99, epsilon 1e-3) (:192). */
+typedef struct cs_train_cfg {
+    float beta1, beta2, adam_eps;
+    float bn_momentum, bn_eps;
+} cs_train_cfg;
+
+/* Number of trainable parameters (84,289) and of BatchNormalization moving statistics (512).
+ * Flat layouts -- trainable: per conv l in order {kernel HWIO, bias, [gamma, beta]};
+ * moving: per BN l in order {moving_mean, moving_variance}. */
+int cs_train_param_count(int64_t *n_trainable, int64_t *n_moving);
+/* init: starting weights + moving statistics (create_improved_autoencoder, :184-229). */
+int cs_train_create(const cs_cae_weights *init, const cs_train_cfg *cfg, int device_id, cs_trainer **out);
+void cs_train_free(cs_trainer *t);
+/* One fit() batch: forward (BN batch statistics, moving-average update), loss = mean((out-y)^2),
+ * mae = mean|out-y|, backward, Adam update with learning rate lr.  x = network input (the
+ * augmented image of datagen.flow(X_train, X_train), :287), y = target; [batch][H][W] fp32. */
+int cs_train_step(cs_trainer *t, const float *x, const float *y, int64_t batch, int kind, float lr,
+                  float *loss, float *mae);
+/* The two halves of cs_train_step, for data-parallel training: gradients are left in the
+ * gradient buffer (all-reduce it between the two calls). */
+int cs_train_forward_backward(cs_trainer *t, const float *x, const float *y, int64_t batch, int kind,
+                              float *loss, float *mae);
+int cs_train_apply(cs_trainer *t, float lr);
+/* Use caller-owned device memory (n_trainable floats, e.g. a torch tensor) as the gradient
+ * buffer; NULL restores the internal one. */
+int cs_train_set_grad_buffer(cs_trainer *t, float *device_buffer);
+/* Inference-mode loss / mae over n cells with the moving statistics (fit()'s validation pass). */
+int cs_train_eval(cs_trainer *t, const float *x, const float *y, int64_t n, int kind, float *loss, float *mae);
+/* Copies to host (each pointer may be NULL): trainable parameters, moving statistics, last gradients. */
+int cs_train_export(cs_trainer *t, float *params_host, float *moving_host, float *grads_host);
+/* Stage tap for parity tests: copies one tensor of the last forward_backward to host.
+ * which: 0 relu(conv) output, 1 BN(+pool) output, 2 dL/dz, 3 dL/d(BN output), 4 sigmoid output. */
+int cs_train_tensor(cs_trainer *t, int which, int layer, int64_t batch, float *host);
+/* Overwrites trainable parameters and/or moving statistics from host arrays (restore best weights). */
+int cs_train_import(cs_trainer *t, const float *params_host, const float *moving_host);
 
 #ifdef __cplusplus
 }

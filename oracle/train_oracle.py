@@ -75,9 +75,15 @@ class TrainState:
         return out
 
 
-def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True):
+def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True, relu_masks=None, pool_args=None):
     """One training-mode forward + backward.  x (aug input), y (target): (N,H,W).
-    Returns dict(loss, mae, out, grads (same order as st.trainables()), batch stats)."""
+    Returns dict(loss, mae, out, grads (same order as st.trainables()), batch stats).
+
+    relu_masks / pool_args (lists per layer, entries may be None) override the two places where
+    the gradient is discontinuous -- ReLU's derivative at z = 0 and MaxPooling2D's routing at a
+    tie -- with another evaluation's decisions (r > 0 masks; arg-max index 0..3 in (dy,dx) order).
+    An fp32 and an fp64 evaluation disagree on a handful of the ~1e6 such decisions per layer
+    (|z| within rounding of 0); gradient parity is only meaningful on the same activation pattern."""
     dt = st.dtype
     x = np.asarray(x, dtype=dt)[..., None]
     y = np.asarray(y, dtype=dt)[..., None]
@@ -108,6 +114,8 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True):
             N, H, W, C = yb.shape
             win = yb.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(N, H // 2, W // 2, C, 4)
             arg = win.argmax(axis=-1)                                            # first max in (dy,dx) order
+            if pool_args is not None and pool_args[l] is not None:
+                arg = np.asarray(pool_args[l])
             h = np.take_along_axis(win, arg[..., None], axis=-1)[..., 0]
             c["arg"] = arg
         else:
@@ -121,6 +129,7 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True):
     grads = [None] * len(st.trainables())
     gi = len(grads)
     dz = (2.0 / n_el) * diff * out * (1.0 - out)
+    dzs, das = [None] * st.n_conv, [None] * st.n_conv
     for l in range(st.n_conv - 1, -1, -1):
         c = cache[l]
         if l < st.n_conv - 1:
@@ -135,16 +144,20 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True):
             dbeta = dyb.sum(axis=(0, 1, 2))
             dgamma = (dyb * c["xhat"]).sum(axis=(0, 1, 2))
             dr = (st.gamma[l] * c["inv"] / nred) * (nred * dyb - dbeta - c["xhat"] * dgamma)
-            dz = dr * (c["r"] > 0)
+            mask = (c["r"] > 0) if (relu_masks is None or relu_masks[l] is None) else np.asarray(relu_masks[l])
+            dz = dr * mask
             gi -= 2
             grads[gi], grads[gi + 1] = dgamma, dbeta
+        dzs[l] = dz
         K = st.kernels[l].reshape(-1, st.kernels[l].shape[3])
         gi -= 2
         grads[gi] = (c["cols"].reshape(-1, K.shape[0]).T @ dz.reshape(-1, K.shape[1])).reshape(st.kernels[l].shape)
         grads[gi + 1] = dz.sum(axis=(0, 1, 2))
         if l > 0:
             dh = _col2im(dz @ K.T, c["cin"], c["ups"])
-    return dict(loss=loss, mae=mae, out=out[..., 0], grads=grads, batch_mean=batch_mean, batch_var=batch_var)
+            das[l - 1] = dh
+    return dict(loss=loss, mae=mae, out=out[..., 0], grads=grads, batch_mean=batch_mean, batch_var=batch_var,
+                dz=dzs, da=das, relu=[c.get("r") for c in cache])
 
 
 def adam_step(st: TrainState, grads, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):

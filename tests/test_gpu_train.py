@@ -1,0 +1,143 @@
+"""Training-step parity: the HIP trainer through the C ABI
+against the numpy oracle (oracle/train_oracle.py, pinned to torch autograd) on the same batch.
+Stated tolerance (Appendix G): per-tensor gradient relative L2 <= 1e-5; loss relative 1e-5."""
+import numpy as np
+import pytest
+
+import helpers as H  # noqa: F401
+from cellscreen import spec, synth
+from cellscreen.trainer import Trainer, flat_from_weights, param_layout, split_flat
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+TOL_GRAD = 1e-5
+
+
+def batch(n, seed=1):
+    y = np.concatenate([synth.blob_crops(seed, n // 2), synth.synth_crops(seed, 0, n - n // 2)])
+    rng = np.random.default_rng(seed)
+    x = np.clip(y + 0.02 * rng.standard_normal(y.shape).astype(np.float32), 0, 1).astype(np.float32)   # augmented input != target
+    return x, y
+
+
+def grads_by_name(flat):
+    return split_flat(flat, param_layout())
+
+
+def activation_pattern(tr, w, n):
+    """The trainer's ReLU masks and max-pool routing, from its relu outputs (stage tap 0).
+    BN is monotone in r (increasing for gamma > 0, decreasing for gamma < 0), so the arg-max of
+    BN(r) over a window is the first arg-max of sign(gamma) * r."""
+    masks, args = [], []
+    for l in range(6):
+        r = tr.tensor(0, l, n)
+        masks.append(r > 0)
+        if l < 3:
+            N, Hh, Ww, C = r.shape
+            win = r.reshape(N, Hh // 2, 2, Ww // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(N, Hh // 2, Ww // 2, C, 4)
+            args.append(np.argmax(win * np.sign(w.bn_gamma[l])[None, None, None, :, None], axis=-1))
+        else:
+            args.append(None)
+    return masks + [None], args + [None] * 4
+
+
+@pytest.mark.parametrize("n", [32, 5])
+def test_forward_backward_gradients(n):
+    w = synth.random_cae(seed=11)
+    x, y = batch(n)
+    tr = Trainer(w)
+    loss, mae = tr.forward_backward(x, y)
+    # ReLU' and max-pool routing are discontinuous: an fp32 and an fp64 evaluation disagree on a
+    # handful of the ~1e6 decisions per layer, so the oracle is run on the trainer's pattern
+    masks, args = activation_pattern(tr, w, n)
+    st = T.TrainState(w, dtype=np.float64)
+    ref = T.forward_backward(st, x, y, relu_masks=masks, pool_args=args)
+    free = T.forward_backward(T.TrainState(w, dtype=np.float64), x, y)
+    flips = sum(int(np.sum(m != (r > 0))) for m, r in zip(masks[:6], free["relu"][:6]))
+    print("ReLU decisions that differ from the unconstrained fp64 oracle:", flips, "of", sum(m.size for m in masks[:6]))
+    assert flips <= 1e-5 * sum(m.size for m in masks[:6])
+    assert abs(loss - ref["loss"]) <= 1e-5 * ref["loss"], (loss, ref["loss"])
+    assert abs(mae - ref["mae"]) <= 1e-5 * ref["mae"]
+    _, mov, g = tr.export_flat(grads=True)
+    got = grads_by_name(g)
+    errs = {}
+    for (name, _shape), gr in zip(param_layout(), ref["grads"]):
+        errs[name] = np.linalg.norm(got[name].astype(np.float64) - gr) / max(np.linalg.norm(gr), 1e-30)
+    print("gradient relative L2 errors:", {k: float("%.2e" % v) for k, v in errs.items()})
+    for name, err in errs.items():
+        assert err <= TOL_GRAD, f"{name}: relative L2 error {err:.3e}" 
+    # moving statistics: momentum 0.99 update with the batch mean / biased variance
+    o = 0
+    for l in range(6):
+        c = spec.CHANNELS[l]
+        assert np.allclose(mov[o:o + c], st.mov_mean[l], rtol=1e-5, atol=1e-7); o += c
+        assert np.allclose(mov[o:o + c], st.mov_var[l], rtol=1e-5, atol=1e-7); o += c
+    tr.close()
+
+
+def test_adam_update_is_keras_formula():
+    """cs_train_apply on the trainer's own gradients == Keras Adam evaluated in float64:
+    alpha = lr*sqrt(1-b2^t)/(1-b1^t); m, v EMAs; w -= alpha*m/(sqrt(v)+1e-7)."""
+    w = synth.random_cae(seed=12, trivial_bn=True)      # Keras init: gamma 1, beta 0, mean 0, var 1
+    x, y = batch(16, seed=3)
+    tr = Trainer(w)
+    p, _ = flat_from_weights(w)
+    p = p.astype(np.float64)
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    for t in range(1, 4):
+        tr.forward_backward(x, y)
+        _, _, g = tr.export_flat(grads=True)
+        tr.apply(lr=1e-3)
+        g = g.astype(np.float64)
+        m += (g - m) * (1 - 0.9); v += (g * g - v) * (1 - 0.999)
+        alpha = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        p = p - alpha * m / (np.sqrt(v) + 1e-7)
+        got, _ = tr.export_flat()
+        assert np.abs(got - p).max() <= 2e-6 * 1e-3 + 1e-6 * np.abs(p).max(), t     # updates are O(lr)
+        p = got.astype(np.float64)   # follow the trainer so the next step checks one update in isolation
+    tr.close()
+
+
+def test_training_trajectory_tracks_the_oracle():
+    """Several full steps.  Adam's early updates are ~lr*sign(g), so fp32 and fp64 trajectories
+    separate at the 1e-3 level within a few steps (the numpy oracle in float32 does the same
+    against itself in float64): the comparison is loose by necessity."""
+    w = synth.random_cae(seed=12, trivial_bn=True)
+    x, y = batch(16, seed=3)
+    st = T.TrainState(w, dtype=np.float64)
+    tr = Trainer(w)
+    for step in range(4):
+        ref = T.train_step(st, x, y, lr=1e-3)
+        loss, _ = tr.step(x, y, lr=1e-3)
+        assert abs(loss - ref["loss"]) <= (1e-5 if step == 0 else 5e-3) * ref["loss"], (step, loss, ref["loss"])
+    # validation-style evaluation with the moving statistics (fit()'s val_loss)
+    l_ref, m_ref = T.evaluate(st, y, y)
+    l_got, m_got = tr.evaluate(y, y)
+    assert abs(l_got - l_ref) <= 1e-2 * l_ref and abs(m_got - m_ref) <= 1e-2 * m_ref
+    # and exactly: the trainer's eval equals the oracle's eval on the trainer's own weights
+    pw = tr.weights()
+    st2 = T.TrainState(pw, dtype=np.float64)
+    l2, m2 = T.evaluate(st2, y, y)
+    assert abs(l_got - l2) <= 1e-5 * l2 and abs(m_got - m2) <= 1e-5 * m2
+    tr.close()
+
+
+def test_loss_decreases_and_export_roundtrip():
+    w = synth.random_cae(seed=13, trivial_bn=True)
+    y = synth.blob_crops(7, 64)
+    tr = Trainer(w)
+    first = tr.step(y[:32], y[:32])[0]
+    for _ in range(30):
+        last = tr.step(y[:32], y[:32])[0]
+    assert last < 0.7 * first, (first, last)
+    p, m = tr.export_flat()
+    ev = tr.evaluate(y, y)
+    tr2 = Trainer(synth.random_cae(seed=99))
+    tr2.load_flat(p, m)
+    assert tr2.evaluate(y, y) == ev
+    # exported weights drive the screening engine to the same reconstruction error
+    from cellscreen.engine import Engine
+    e = Engine.from_weights(tr.weights())
+    _, mse, _ = e.reconstruct(y, want_recon=False)
+    assert abs(float(mse.mean()) - ev[0]) <= 1e-5 * ev[0]
+    e.close(); tr.close(); tr2.close()
