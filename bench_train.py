@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""bench_train.py -- BASELINE.json configs[1]: CAE training (Conv2D enc/dec, MSE loss) on 50k
+synthetic 64x64 crops, fp32, one MI355X.  Secondary benchmark (the headline metric is
+bench.py's screening rate).  One "step" = one fit() batch of 32 crops: forward with
+BatchNormalization in training mode, MSE loss, backward, Adam -- CAE_improved_modeltrain.py:286-293.
+Crops are resident in HBM; the 80/20 split gives 1250 steps per epoch as in the reference.
+
+    python bench_train.py [--steps K] [--warmup W] [--batch 32] [--gpus N via torchrun]
+With N > 1 ranks each rank trains on its own batch and the 337 KB gradient is averaged with one
+RCCL all-reduce per step (BatchNormalization statistics stay per-rank, Keras's default under
+data parallelism)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "cell-image-analysis_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FLOP_PER_CELL_STEP = 3 * 100_270_080     # forward + backward-data + backward-weight (conv MACs x2 each)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1250)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--cells", type=int, default=50_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench_train.py needs an MI355X")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from cellscreen import dist as csdist
+    from cellscreen import synth
+    from cellscreen.trainer import Trainer
+
+    n_train = int(args.cells * 0.8)
+    X = torch.from_numpy(synth.blob_crops(42 + rank, min(n_train, 4096))).to(dev)   # structured crops; reused cyclically
+    reps = (n_train + len(X) - 1) // len(X)
+    X = X.repeat(reps, 1, 1)[:n_train].contiguous()
+    tr = Trainer(synth.random_cae(seed=42, trivial_bn=True), device_id=local_rank)
+    g = torch.zeros(tr.n_trainable, dtype=torch.float32, device=dev)
+    if world > 1:
+        tr.use_grad_tensor(g)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+
+    def step():
+        idx = torch.randint(0, n_train, (args.batch,), device=dev, generator=gen)
+        xb = X[idx].contiguous()
+        torch.cuda.synchronize()
+        if world > 1:
+            l, _ = tr.forward_backward(xb, xb)
+            csdist.allreduce_mean_(g)
+            torch.cuda.synchronize()
+            tr.apply(1e-3)
+        else:
+            l, _ = tr.step(xb, xb, 1e-3)
+        return l
+
+    first = None
+    for _ in range(args.warmup):
+        l = step(); first = l if first is None else first
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t.item())
+    if rank == 0:
+        cells = args.steps * args.batch * world
+        line = {"metric": "cells/sec trained (CAE fwd+bwd+Adam, batch 32, fp32)", "value": round(cells / el, 1), "unit": "cells/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE.json configs[1]: CAE training on 50k synthetic 64x64 crops (40k train), batch %d per GPU" % args.batch,
+                           "batch_per_gpu": args.batch, "steps_per_epoch": n_train // args.batch, "parallelism": "dp%d" % world},
+                "tflops_algorithmic": round(cells / el * FLOP_PER_CELL_STEP / 1e12 / world, 3),
+                "epoch_seconds_at_1250_steps": round(el / args.steps * 1250, 3),
+                "loss_first_last": [round(first, 6), round(last, 6)]}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import train_oracle as T
+            st = T.TrainState(synth.random_cae(seed=42, trivial_bn=True), dtype=np.float32)
+            xb = X[:args.batch].cpu().numpy()
+            T.train_step(st, xb, xb)
+            t0 = time.perf_counter(); nrep = 5
+            for _ in range(nrep):
+                T.train_step(st, xb, xb)
+            dt = (time.perf_counter() - t0) / nrep
+            line["cpu_baseline"] = {"value": round(args.batch / dt, 1), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
+                                    "sample": "%d steps of batch %d, oracle/train_oracle.py (numpy float32, BLAS threads)" % (nrep, args.batch)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    tr.close()
+
+
+if __name__ == "__main__":
+    main()

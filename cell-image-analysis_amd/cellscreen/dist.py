@@ -52,3 +52,13 @@ def gather_results(local: Dict, n_total: int, group=None, dst: Optional[int] = N
 def to_torch(local_np: Dict, device="cpu") -> Dict:
     import torch
     return {k: torch.as_tensor(np.ascontiguousarray(v), device=device) for k, v in local_np.items()}
+
+
+def allreduce_mean_(t, group=None):
+    """In-place mean over ranks of a flat gradient tensor: each rank's loss is the mean over its
+    local batch, so the gradient of the global-batch mean is the average of the per-rank
+    gradients (one RCCL all-reduce of 337 KB per step; latency-bound)."""
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= dist.get_world_size(group)
+    return t

@@ -57,3 +57,33 @@ def test_gather_world2_gloo(n_total):
     assert np.array_equal(got["cons_score"], idx.astype(np.float64) - 3.0)
     assert np.array_equal(got["cons_pred"], np.where(idx % 3 == 0, -1, 1).astype(np.int8))
     assert got["mod_pred"].dtype == np.int8 and len(got["mod_score"]) == n_total
+
+
+def _grad_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.arange(84289, dtype=torch.float32) * (rank + 1)
+    csdist.allreduce_mean_(g)
+    if rank == 0:
+        q.put(g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_world2_gloo():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got, np.arange(84289, dtype=np.float32) * 1.5)

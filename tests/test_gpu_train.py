@@ -141,3 +141,35 @@ def test_loss_decreases_and_export_roundtrip():
     _, mse, _ = e.reconstruct(y, want_recon=False)
     assert abs(float(mse.mean()) - ev[0]) <= 1e-5 * ev[0]
     e.close(); tr.close(); tr2.close()
+
+
+def test_training_class_mirror(tmp_path):
+    """ImprovedAnomalyDetectionTraining: split 80/20 seed 42, callbacks, files, detector, and the
+    resulting model_dir loads in the screening class (CAE_improved_modeltrain.py:480-505 flow)."""
+    from cellscreen.screening import ProductionMutantScreening
+    from cellscreen.training import ImprovedAnomalyDetectionTraining
+    cells = synth.blob_crops(21, 640)
+    out = str(tmp_path / "models")
+    t = ImprovedAnomalyDetectionTraining(out, epochs=3, verbose=0)
+    autoencoder, encoder, history = t.train_autoencoder(cells)
+    h = history.history
+    assert len(h["loss"]) == 3 and h["loss"][-1] < h["loss"][0] and len(h["val_loss"]) == 3
+    assert encoder.n_conv == 3 and autoencoder.n_conv == 7
+    assert os.path.exists(os.path.join(out, "best_autoencoder", "cae.bin"))
+    assert os.path.exists(os.path.join(out, "final_autoencoder", "cae.bin"))
+    mse, mae = t.evaluate_reconstruction_quality(autoencoder, cells)
+    assert mse.shape == (640,) and mse.dtype == np.float32
+    detectors, scaler, pca = t.create_anomaly_detector(encoder, cells, autoencoder=autoencoder)
+    assert set(detectors) == {"Conservative", "Moderate"} and pca.n_components_ == 100
+    for f in ("scaler.pkl", "pca.pkl", "detector_conservative.pkl", "detector_moderate.pkl", "cae.bin", "detector.bin"):
+        assert os.path.exists(os.path.join(out, f)), f
+    s = ProductionMutantScreening(out)
+    r = s.compute_anomaly_scores(list(cells[:50]))
+    # the detector was fit on these cells: scores reproduce sklearn's own decision_function
+    feats = s.engine.encode(cells[:50], which=1)
+    dec = detectors["Conservative"].decision_function(pca.transform(scaler.transform(feats.copy())))
+    assert np.abs(-r["conservative_scores"] - dec).max() <= 1e-4 * np.abs(detectors["Conservative"].dual_coef_).sum()
+    assert 0.0 <= r["conservative_anomaly_rate"] <= 0.5
+
+
+import os  # noqa: E402
