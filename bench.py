@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=1_000_000, help="crops per GPU per step")
-    ap.add_argument("--chunk", type=int, default=16384, help="cells per internal pass")
+    ap.add_argument("--chunk", type=int, default=65536, help="cells per internal pass (workspace ~0.4 MB per cell)")
     ap.add_argument("--train-cells", type=int, default=5000, help="synthetic crops the detector is fit on")
     ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,8 +157,22 @@ def main():
         d = kern[dom]
         avg_ms = d["ms"] / d["launches"]
         ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+        # HBM traffic of that kernel: measured with rocprofv3 PMC passes (tools/pmc_traffic.py; a profiler
+        # cannot run inside this process), bytes per cell x the cells this launch processed
+        traffic, traffic_src = None, None
+        try:
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            if pmc:
+                tj = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+                if dom in tj["kernels"]:
+                    traffic = round(tj["kernels"][dom]["hbm_bytes_per_cell"] * (d["cells"] / d["launches"]))
+                    traffic_src = "profiles/" + pmc[-1]
+        except Exception:
+            pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch",
+                        traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=int((131072 + 65536) * (d["cells"] / d["launches"])) if dom.startswith("conv2") else None,
                         avg_launch_ms=round(avg_ms, 4), cells_per_launch=d["cells"] // d["launches"],
                         share_of_device_time=round(d["ms"] / total_ms, 4))
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], share=round(v["ms"] / total_ms, 4),

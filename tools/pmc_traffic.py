@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950:
+MI355X_MICROARCH.md "rocprofv3 PMC slots") into per-kernel HBM traffic per cell.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 16384 > profiles/rNN_pmc_traffic.json
+
+Corrections, as the guide prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE
+is exact for 16-B-per-lane stores and uncalibrated for our 4-B-per-lane epilogue stores (it
+comes out within 2 % of the algorithmic byte count, so it is taken as is).  Only full-chunk
+launches are used (the detector-fit encode pass and the tail chunk are filtered by duration)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+KERNELS = [("ConvCfg<64, 64, 1, 32, 1", "conv1_relu_bn_pool"), ("ConvCfg<32, 32, 32, 64, 1", "conv2_relu_bn_pool"),
+           ("ConvCfg<16, 16, 64, 32, 1", "conv3_relu_bn_pool"), ("ConvCfg<8, 8, 32, 32, 0", "conv4_relu_bn"),
+           ("ConvCfg<16, 16, 32, 64, 0", "conv5_up_relu_bn"), ("ConvCfg<32, 32, 64, 32, 0", "conv6_up_relu_bn"),
+           ("conv7_err_kernel", "conv7_up_sigmoid_err"), ("scaler_pca_kernel", "scaler_pca"), ("ocsvm_reg_kernel", "ocsvm_decision")]
+
+
+def per_kernel(d, counter, chunk):
+    rows = list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])))
+    by = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            by[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for pat, name in KERNELS:
+        for k, v in by.items():
+            if pat in k:
+                longest = max(x[1] for x in v)
+                full = [x for x in v if x[1] > 0.7 * longest]          # full-chunk launches only
+                out[name] = dict(kib_per_launch=sum(x[0] for x in full) / len(full), launches=len(full),
+                                 avg_ms=sum(x[1] for x in full) / len(full) / 1e6)
+    return out
+
+
+def main():
+    fetch_dir, write_dir, chunk = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    f = per_kernel(fetch_dir, "FETCH_SIZE", chunk)
+    w = per_kernel(write_dir, "WRITE_SIZE", chunk)
+    res = {"cells_per_launch": chunk, "note": "HBM bytes per cell = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / cells_per_launch", "kernels": {}}
+    for _, name in KERNELS:
+        if name in f and name in w:
+            rd = 2.0 * f[name]["kib_per_launch"] * 1024 / chunk
+            wr = w[name]["kib_per_launch"] * 1024 / chunk
+            res["kernels"][name] = dict(read_bytes_per_cell=round(rd, 1), write_bytes_per_cell=round(wr, 1),
+                                        hbm_bytes_per_cell=round(rd + wr, 1), avg_launch_ms_under_pmc=round(f[name]["avg_ms"], 4))
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
