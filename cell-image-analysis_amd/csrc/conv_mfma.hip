@@ -226,7 +226,15 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         char* nstrip = smem + (C::MODE == STAGE_DB ? (buf ^ 1) * C::STRIP_BYTES : 0);
 
         // ---- tile pairs ----------------------------------------------------------
-        auto pair_tiles = [&](int p, int& t0, int& t1) {
+        int pi = 0;
+        for (int p = mg; p < C::NPAIR; p += C::NMG, ++pi) {
+            if constexpr (C::MODE == STAGE_DB) {
+                if (has_next) {   // this iteration's slice of the next strip: loads now, LDS writes at the bottom
+#pragma unroll
+                    for (int j = 0; j < C::LPP; ++j) stg[j] = S::load(in, ncell, ny0, tid + 256 * (pi * C::LPP + j));
+                }
+            }
+            int t0, t1;
             if constexpr (C::POOL) {  // vertical pool partners: same columns, rows 2r and 2r+1
                 const int ry = 2 * (p / C::TPR), xb = p % C::TPR;
                 t0 = ry * C::TPR + xb;
@@ -235,9 +243,58 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 t0 = 2 * p;
                 t1 = 2 * p + 1;
             }
-        };
-        // epilogue: D[row = 4*kq + r][col = li] -> per-mode transform, store
-        auto epilogue = [&](int t0, int t1, const f32x4& acc0, const f32x4& acc1) {
+            int py0, px0, py1, px1;
+            tile_pixel<C>(t0, li, py0, px0);
+            tile_pixel<C>(t1, li, py1, px1);
+
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (C::CIN == 1) {
+                const int b0 = (py0 * C::WP + px0) * 4, b1 = (py1 * C::WP + px1) * 4;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    float a0 = *(const float*)(strip + b0 + toff[s]);
+                    float a1 = *(const float*)(strip + b1 + toff[s]);
+                    a0 = tval[s] ? a0 : 0.0f;
+                    a1 = tval[s] ? a1 : 0.0f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
+                }
+            } else {
+                // K walk in groups g = (tap, 16-channel block): one 16-B LDS read per tile feeds 4 MFMAs.
+                // The reads of group g+1 are issued before the MFMAs of group g (software prefetch),
+                // so the matrix pipe never waits on an LDS round trip.
+                constexpr int G = 9 * C::KQ;
+                int ad0[9], ad1[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    ad0[tap] = a_addr<C>(py0, px0, kq, tap);
+                    ad1[tap] = a_addr<C>(py1, px1, kq, tap);
+                }
+                f32x4 a0 = *(const f32x4*)(strip + ad0[0]);
+                f32x4 a1 = *(const f32x4*)(strip + ad1[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // group 0's reads
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    f32x4 n0 = a0, n1 = a1;
+                    if (g + 1 < G) {
+                        n0 = *(const f32x4*)(strip + ad0[(g + 1) / C::KQ] + ((g + 1) % C::KQ) * 64);
+                        n1 = *(const f32x4*)(strip + ad1[(g + 1) / C::KQ] + ((g + 1) % C::KQ) * 64);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float b = B[g * 4 + j];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc1, 0, 0, 0);
+                    }
+                    a0 = n0;
+                    a1 = n1;
+                    // pin the schedule: this group's 2 prefetch reads first, then its 8 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                }
+            }
+
+            // ---- epilogue: D[row = 4*kq + r][col = li] -> per-mode transform, store
             auto post = [&](float v) -> float {
                 if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) return relu_bn(v, bias, bns, bnt);
                 else if constexpr (C::EPI == EPI_RELU) return fmaxf(v + bias, 0.0f);
@@ -273,125 +330,13 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                     out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = post(acc1[r]);
                 }
             }
-        };
 
-        if constexpr (C::CIN == 1) {
-            for (int p = mg; p < C::NPAIR; p += C::NMG) {
-                int t0, t1, py0, px0, py1, px1;
-                pair_tiles(p, t0, t1);
-                tile_pixel<C>(t0, li, py0, px0);
-                tile_pixel<C>(t1, li, py1, px1);
-                f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const int b0 = (py0 * C::WP + px0) * 4, b1 = (py1 * C::WP + px1) * 4;
+            if constexpr (C::MODE == STAGE_DB) {
+                if (has_next) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    float a0 = *(const float*)(strip + b0 + toff[s]);
-                    float a1 = *(const float*)(strip + b1 + toff[s]);
-                    a0 = tval[s] ? a0 : 0.0f;
-                    a1 = tval[s] ? a1 : 0.0f;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
+                    for (int j = 0; j < C::LPP; ++j) S::store(nstrip, tid + 256 * (pi * C::LPP + j), stg[j]);
                 }
-                epilogue(t0, t1, acc0, acc1);
             }
-        } else {
-            // The pair loop is software pipelined: the epilogue (VALU + stores) of pair i runs inside
-            // the MFMA stream of pair i+1, and the A-operand addresses and first LDS reads of pair
-            // i+1 are issued before the last MFMA group of pair i, so the matrix pipe keeps issuing
-            // across pairs (measured before: ~1000 pipe cycles idle per pair).
-            // K walk in groups g = (tap, 16-channel block): one 16-B LDS read per tile feeds 4 MFMAs;
-            // the reads of group g+1 are issued before the MFMAs of group g.
-            constexpr int G = 9 * C::KQ;
-            // A-operand addressing.  Not upsampled: per-lane tile base + a compile-time tap offset that
-            // folds into the ds_read immediate.  Upsampled: the column part ((x+dx)>>1) is per lane
-            // (3 values per tile), the row part ((y+dy)>>1) is wave-uniform (a tile is one conv row).
-            int t0, t1;
-            int base0 = 0, base1 = 0;            // !UPS
-            int col0[3], col1[3], row0[3], row1[3];   // UPS
-            f32x4 a0, a1;
-            auto addr = [&](int tile, int tap) -> int {
-                const int dy = tap / 3, dx = tap % 3;   // 0..2
-                if constexpr (C::UPS) return (tile ? col1[dx] + row1[dy] : col0[dx] + row0[dy]);
-                else return (tile ? base1 : base0) + (dy * C::WP + dx) * (C::PS * 4);
-            };
-            auto setup = [&](int p) {   // tiles, addressing and the first reads of pair p
-                pair_tiles(p, t0, t1);
-                int py0, px0, py1, px1;
-                tile_pixel<C>(t0, li, py0, px0);
-                tile_pixel<C>(t1, li, py1, px1);
-                if constexpr (C::UPS) {
-                    const int sy0 = __builtin_amdgcn_readfirstlane(py0), sy1 = __builtin_amdgcn_readfirstlane(py1);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        col0[d] = (((px0 + d - 1) >> 1) + 1) * (C::PS * 4) + kq * 16;
-                        col1[d] = (((px1 + d - 1) >> 1) + 1) * (C::PS * 4) + kq * 16;
-                        row0[d] = (((sy0 + d - 1) >> 1) + 1) * (C::WP * C::PS * 4);
-                        row1[d] = (((sy1 + d - 1) >> 1) + 1) * (C::WP * C::PS * 4);
-                    }
-                } else {
-                    base0 = (py0 * C::WP + px0) * (C::PS * 4) + kq * 16;
-                    base1 = (py1 * C::WP + px1) * (C::PS * 4) + kq * 16;
-                }
-                a0 = *(const f32x4*)(strip + addr(0, 0));
-                a1 = *(const f32x4*)(strip + addr(1, 0));
-            };
-            f32x4 pacc0 = {0.0f, 0.0f, 0.0f, 0.0f}, pacc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-            int pt0 = 0, pt1 = 0;
-            // One pair.  with_prev: the previous pair's epilogue is interleaved after the first MFMA
-            // group; with_next: the next pair's addressing and first reads go before the last group.
-            auto pair_body = [&](int pi, auto with_prev, auto with_next) {
-                if constexpr (C::MODE == STAGE_DB) {
-                    if (has_next) {   // this iteration's slice of the next strip: loads now, LDS writes at the bottom
-#pragma unroll
-                        for (int j = 0; j < C::LPP; ++j) stg[j] = S::load(in, ncell, ny0, tid + 256 * (pi * C::LPP + j));
-                    }
-                }
-                f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const int ct0 = t0, ct1 = t1;
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // group 0's reads (issued by setup)
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32x4 c0 = a0, c1 = a1;   // this group's operands
-                    f32x4 n0 = c0, n1 = c1;
-                    if (g + 1 < G) {
-                        n0 = *(const f32x4*)(strip + addr(0, (g + 1) / C::KQ) + ((g + 1) % C::KQ) * 64);
-                        n1 = *(const f32x4*)(strip + addr(1, (g + 1) / C::KQ) + ((g + 1) % C::KQ) * 64);
-                    } else if constexpr (decltype(with_next)::value) {
-                        setup(mg + (pi + 1) * C::NMG);   // next pair: addressing + first reads (into a0/a1)
-                        n0 = a0;
-                        n1 = a1;
-                    }
-                    if constexpr (decltype(with_prev)::value) {
-                        if (g == 1) epilogue(pt0, pt1, pacc0, pacc1);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float b = B[g * 4 + j];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[j], b, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[j], b, acc1, 0, 0, 0);
-                    }
-                    a0 = n0;
-                    a1 = n1;
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                }
-                pacc0 = acc0; pacc1 = acc1; pt0 = ct0; pt1 = ct1;
-                if constexpr (C::MODE == STAGE_DB) {
-                    if (has_next) {
-#pragma unroll
-                        for (int j = 0; j < C::LPP; ++j) S::store(nstrip, tid + 256 * (pi * C::LPP + j), stg[j]);
-                    }
-                }
-            };
-            setup(mg);
-            if constexpr (C::PPW == 1) {
-                pair_body(0, std::false_type{}, std::false_type{});
-            } else {
-                pair_body(0, std::false_type{}, std::true_type{});
-                for (int pi = 1; pi < C::PPW - 1; ++pi) pair_body(pi, std::true_type{}, std::true_type{});
-                pair_body(C::PPW - 1, std::true_type{}, std::false_type{});
-            }
-            epilogue(pt0, pt1, pacc0, pacc1);
         }
         __syncthreads();  // all reads of this strip done; (STAGE_DB) next strip complete in the other buffer
         buf ^= 1;
