@@ -31,7 +31,12 @@ for p in (os.path.join(ROOT, "cell-image-analysis_amd"), ROOT):
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0              # spec
-FLOP_PER_CELL = 100_270_080        # 2 x 50,135,040 conv MACs, SURVEY.md section 8d
+FLOP_PER_CELL = 100_270_080        # ALGORITHMIC: 2 x 50,135,040 conv MACs of the reference graph, SURVEY.md section 8d
+# EXECUTED multiply-adds as a fraction of the algorithmic ones, per kernel: the three convs behind an
+# UpSampling2D are evaluated as four 2x2-tap phase convs with pre-summed weights (exact algebra,
+# 4/9 of the MACs); conv1 pads K = 9 to 12 for the 16x16x4 MFMA.
+EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0, "conv5_up_relu_bn": 4.0 / 9.0, "conv6_up_relu_bn": 4.0 / 9.0,
+                 "conv7_up_sigmoid_err": 4.0 / 9.0}
 BYTES_PER_CELL = 16_384 + 18       # algorithmic: read one crop, write 4 fp32/fp64-as-results + 2 int8
 
 
@@ -176,8 +181,11 @@ def main():
                         avg_launch_ms=round(avg_ms, 4), cells_per_launch=d["cells"] // d["launches"],
                         share_of_device_time=round(d["ms"] / total_ms, 4))
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], share=round(v["ms"] / total_ms, 4),
-                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None)
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
+                           tflops_executed=round(v["flops"] * EXEC_FRACTION.get(k, 1.0) / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None)
                    for k, v in kern.items()}
+        exec_flop_per_cell = sum(kern[k]["flops"] * EXEC_FRACTION.get(k, 1.0) for k in kern if k.startswith("conv")) / max(
+            1, kern["conv2_relu_bn_pool"]["cells"])
         line = {
             "metric": "cells/sec screened (CAE fwd + recon-MSE + SVM score), 64x64",
             "value": round(value, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,6 +200,9 @@ def main():
                        "parallelism": "dp%d" % world},
             "whole_path": {"tflops_algorithmic": round(value * FLOP_PER_CELL / 1e12 / world, 3),
                            "frac_fp32_mfma_peak": round(value * FLOP_PER_CELL / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "tflops_executed": round(value * exec_flop_per_cell / 1e12 / world, 3),
+                           "frac_fp32_mfma_peak_executed": round(value * exec_flop_per_cell / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "note": "algorithmic = the reference graph's 100.27 MFLOP/cell; executed counts the folded-upsample convs at 4/9",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
                            "device_ms_per_step": round(total_ms / args.steps, 3)},

@@ -115,9 +115,11 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
     std::vector<float> tmp;
     for (int l = 0; l < count; ++l) {
         const int cin = l == 0 ? 1 : kRefChannels[l - 1], cout = kRefChannels[l];
-        const size_t nf = pack_conv_fragments(cin, cout, nullptr, nullptr);
+        const bool folded = (l == 4 || l == 5);   // decoder convs behind an UpSampling2D (conv7 folds in conv_out.hip)
+        const size_t nf = folded ? pack_conv_fragments_folded(cin, cout, nullptr, nullptr) : pack_conv_fragments(cin, cout, nullptr, nullptr);
         tmp.resize(nf);
-        pack_conv_fragments(cin, cout, w->kernel[l], tmp.data());
+        if (folded) pack_conv_fragments_folded(cin, cout, w->kernel[l], tmp.data());
+        else pack_conv_fragments(cin, cout, w->kernel[l], tmp.data());
         int rc = upload(set.wfrag[l], tmp.data(), nf * sizeof(float));
         if (rc) return rc;
         std::vector<float> ep(3 * cout);
@@ -248,7 +250,7 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     for (int l = first; l <= last && l < 6; ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         LAUNCH(K_CONV1 + l, nc,
-               launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+               launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, l == 4 || l == 5));
     }
     if (last >= 6)
         LAUNCH(K_CONV7_ERR, nc,

@@ -26,8 +26,11 @@ enum KernelId {
 // conv layers 1..6 of the 64x64 reference graph; `layer` is 0-based.
 // in/out NHWC fp32; wfrag = MFMA B-operand fragments built by pack_conv_fragments();
 // ep = [3][cout] {bias, bn_scale, bn_shift}.
+// folded = true (layers 4 and 5 only): wfrag comes from pack_conv_fragments_folded and the
+// upsample is folded into four 2x2-tap phase convs (4/9 of the MACs).
 hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, const float* ep,
-                            float* out, int64_t n_cells, hipStream_t stream);
+                            float* out, int64_t n_cells, hipStream_t stream, bool folded = false);
+size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* dst);
 // Host-side packing of HWIO weights into the per-lane B fragments of launch_conv_mfma.
 // Returns the number of floats written (or required if dst == nullptr).
 size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);

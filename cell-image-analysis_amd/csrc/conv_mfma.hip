@@ -45,14 +45,24 @@ enum { STAGE_PF = 1, STAGE_DB = 2 };
 //   EPI_SUMPOOL  2x2 sum (adjoint of UpSampling2D nearest)       training: same, through an upsample
 enum { EPI_BN = 0, EPI_BN_POOL = 1, EPI_RELU = 2, EPI_PLAIN = 3, EPI_SUMPOOL = 4 };
 
-template <int H_, int W_, int CIN_, int COUT_, int EPI_, bool UPS_, int SR_, int WPS_, int MODE_>
+// FOLD_ (upsampled layers only): nearest x2 upsampling makes the 3x3 taps of output pixel
+// (2y+a, 2x+b) land on only 2x2 stored pixels, so the conv splits into 4 output phases (a,b), each
+// a 2x2-tap conv over the STORED grid with the taps that share a stored pixel pre-summed
+// (W_eff[a][b][ry][rx] = sum of W[dy][dx] over the taps mapping there).  Exact algebra, 4/9 of
+// the multiply-adds; only the order of fp32 roundings changes.  Tiles are phase-pure (16 stored
+// pixels, outputs at stride 2), the tap offsets are compile-time immediates again (no >>1).
+template <int H_, int W_, int CIN_, int COUT_, int EPI_, bool UPS_, int SR_, int WPS_, int MODE_, bool FOLD_ = false>
 struct ConvCfg {
+    static constexpr bool FOLD = FOLD_;
     static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_, SR = SR_, WPS = WPS_, MODE = MODE_, EPI = EPI_;
     static constexpr bool POOL = (EPI_ == EPI_BN_POOL || EPI_ == EPI_SUMPOOL), UPS = UPS_;
     static constexpr int NSL = COUT / 16;            // 16-channel output slices (= waves along N)
     static constexpr int NMG = 4 / NSL;              // wave groups along M
     static constexpr int KQ = CIN / 16;              // 16-channel K blocks per tap (0 when CIN == 1)
-    static constexpr int NB = (CIN == 1) ? 3 : 9 * KQ * 4;  // B fragment registers per lane
+    // FOLD: a wave holds the effective weights of PHW phases: both column phases b, and either its
+    // own row phase a (NMG == 2: the M group IS the row phase) or both (NMG == 1)
+    static constexpr int PHW = (4 / (COUT / 16) == 2) ? 2 : 4;
+    static constexpr int NB = (CIN == 1) ? 3 : (FOLD_ ? PHW * 4 * (CIN / 16) * 4 : 9 * (CIN / 16) * 4);  // B fragment registers per lane
     static constexpr int HS = UPS ? H / 2 : H;       // stored input size
     static constexpr int WS = UPS ? W / 2 : W;
     static constexpr int R = UPS ? SR / 2 + 2 : SR + 2;     // staged rows (incl. halo)
@@ -77,6 +87,7 @@ struct ConvCfg {
     static_assert(TILES % 2 == 0 && NPAIR % NMG == 0, "strip must split into tile pairs");
     static_assert(H % SR == 0 && SR % 2 == 0, "strip rows");
     static_assert(MODE == STAGE_PF || MODE == STAGE_DB, "staging mode");
+    static_assert(!FOLD_ || (UPS_ && (EPI_ == EPI_BN || EPI_ == EPI_RELU) && CIN_ >= 16), "FOLD needs an upsampled, unpooled layer");
     static_assert(LDS_BYTES <= 160 * 1024, "strip does not fit the 160 KB LDS");
 };
 
@@ -167,7 +178,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     // B fragments: this wave's [K x 16] weight slice, resident in registers.
     float B[C::NB];
 #pragma unroll
-    for (int s = 0; s < C::NB; ++s) B[s] = wfrag[((size_t)nsl * C::NB + s) * 64 + lane];
+    for (int s = 0; s < C::NB; ++s) {
+        if constexpr (C::FOLD && C::NMG == 2) B[s] = wfrag[(((size_t)nsl * 2 + mg) * C::NB + s) * 64 + lane];   // [slice][a][b][tap]...
+        else B[s] = wfrag[((size_t)nsl * C::NB + s) * 64 + lane];
+    }
 
     const int co = nsl * 16 + li;
     float bias = 0.0f, bns = 1.0f, bnt = 0.0f;
@@ -225,6 +239,79 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         const char* strip = smem + (C::MODE == STAGE_DB ? buf * C::STRIP_BYTES : 0);
         char* nstrip = smem + (C::MODE == STAGE_DB ? (buf ^ 1) * C::STRIP_BYTES : 0);
 
+        // ---- folded upsample conv: phase-pure tile pairs ((a,0),(a,1)) over stored pixels -------
+        if constexpr (C::FOLD) {
+            constexpr int SRS = C::SR / 2;                                   // stored rows in the strip
+            constexpr int RPT = (C::WS >= 16) ? 1 : 16 / C::WS;              // stored rows per tile
+            constexpr int TPRS = (C::WS >= 16) ? C::WS / 16 : 1;             // tiles per stored row
+            constexpr int NT = (SRS / RPT) * TPRS;                           // tiles per strip and phase
+            constexpr int NA = (C::NMG == 2) ? 1 : 2;                        // row phases this wave walks
+            constexpr int GK = 4 * C::KQ;                                    // K groups per tile: 4 taps x 16-ch blocks
+            static_assert(SRS % RPT == 0, "strip rows");
+            int pi = 0;
+            for (int ai = 0; ai < NA; ++ai) {
+                const int a = (C::NMG == 2) ? mg : ai;                       // row phase (wave-uniform)
+                for (int t = 0; t < NT; ++t, ++pi) {
+                    if constexpr (C::MODE == STAGE_DB) {
+                        if (has_next) {
+#pragma unroll
+                            for (int j = 0; j < C::LPP; ++j) stg[j] = S::load(in, ncell, ny0, tid + 256 * (pi * C::LPP + j));
+                        }
+                    }
+                    // stored pixel of lane li in tile t
+                    int ys, xs;
+                    if constexpr (C::WS >= 16) { ys = t / TPRS; xs = (t % TPRS) * 16 + li; }
+                    else { ys = t * RPT + li / C::WS; xs = li % C::WS; }
+                    // LDS row 0 is stored row -1: stored (ys + a - 1 + ry, xs + b - 1 + rx) -> LDS (ys + a + ry, xs + b + rx)
+                    const int base = ((ys + a) * C::WP + xs) * (C::PS * 4) + kq * 16;
+                    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};   // column phases b = 0, 1
+                    auto rd = [&](int b, int g) -> f32x4 {
+                        const int tap = g / C::KQ, q = g % C::KQ, ry = tap >> 1, rx = tap & 1;
+                        return *(const f32x4*)(strip + base + (ry * C::WP + b + rx) * (C::PS * 4) + q * 64);
+                    };
+                    f32x4 a0 = rd(0, 0), a1 = rd(1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int g = 0; g < GK; ++g) {
+                        f32x4 n0 = a0, n1 = a1;
+                        if (g + 1 < GK) { n0 = rd(0, g + 1); n1 = rd(1, g + 1); }
+                        const int pw0 = (C::NMG == 2) ? 0 : ai * 2, pw1 = pw0 + 1;   // phase slots of b = 0, 1
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], B[(pw0 * GK + g) * 4 + j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], B[(pw1 * GK + g) * 4 + j], acc1, 0, 0, 0);
+                        }
+                        a0 = n0;
+                        a1 = n1;
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    }
+                    // epilogue: D row 4*kq + r -> stored pixel -> output (2*ys + a, 2*xs + b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i2 = 4 * kq + r;
+                        int ys2, xs2;
+                        if constexpr (C::WS >= 16) { ys2 = t / TPRS; xs2 = (t % TPRS) * 16 + i2; }
+                        else { ys2 = t * RPT + i2 / C::WS; xs2 = i2 % C::WS; }
+                        const int Y = y0 + 2 * ys2 + a, X = 2 * xs2;
+                        float* o = out + (((size_t)cell * C::HO + Y) * C::WO + X) * C::COUT + co;
+                        if constexpr (C::EPI == EPI_RELU) {
+                            o[0] = fmaxf(acc0[r] + bias, 0.0f);
+                            o[C::COUT] = fmaxf(acc1[r] + bias, 0.0f);
+                        } else {
+                            o[0] = relu_bn(acc0[r], bias, bns, bnt);
+                            o[C::COUT] = relu_bn(acc1[r], bias, bns, bnt);
+                        }
+                    }
+                    if constexpr (C::MODE == STAGE_DB) {
+                        if (has_next) {
+#pragma unroll
+                            for (int j = 0; j < C::LPP; ++j) S::store(nstrip, tid + 256 * (pi * C::LPP + j), stg[j]);
+                        }
+                    }
+                }
+            }
+        } else {
         // ---- tile pairs ----------------------------------------------------------
         int pi = 0;
         for (int p = mg; p < C::NPAIR; p += C::NMG, ++pi) {
@@ -338,6 +425,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 }
             }
         }
+        }   // !FOLD
         __syncthreads();  // all reads of this strip done; (STAGE_DB) next strip complete in the other buffer
         buf ^= 1;
     }
@@ -351,6 +439,9 @@ using CfgL3 = ConvCfg<16, 16, 64, 32, EPI_BN_POOL, false,  4, 2, STAGE_DB>;   //
 using CfgL4 = ConvCfg< 8,  8, 32, 32, EPI_BN,      false,  8, 3, STAGE_PF>;   // :204-205
 using CfgL5 = ConvCfg<16, 16, 32, 64, EPI_BN,      true,  16, 3, STAGE_PF>;   // :206-209 (reads up(a4))
 using CfgL6 = ConvCfg<32, 32, 64, 32, EPI_BN,      true,   8, 2, STAGE_DB>;   // :210-213 (reads up(a5))
+// the same two decoder layers with the upsample folded into 4 phase convs (4/9 of the MACs)
+using CfgL5F = ConvCfg<16, 16, 32, 64, EPI_BN,     true,  16, 2, STAGE_PF, true>;
+using CfgL6F = ConvCfg<32, 32, 64, 32, EPI_BN,     true,   8, 2, STAGE_DB, true>;
 // training forward: conv + bias + ReLU at full conv-grid resolution (BN batch stats come next)
 using CfgF1 = ConvCfg<64, 64,  1, 32, EPI_RELU,    false, 16, 4, STAGE_PF>;
 using CfgF2 = ConvCfg<32, 32, 32, 64, EPI_RELU,    false,  4, 3, STAGE_PF>;
@@ -396,8 +487,10 @@ static hipError_t launch_cfg(const float* in, const float* wfrag, const float* e
 }
 
 hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, const float* ep,
-                            float* out, int64_t n_cells, hipStream_t stream)
+                            float* out, int64_t n_cells, hipStream_t stream, bool folded)
 {
+    if (folded && layer == 4) return launch_cfg<CfgL5F>(in, wfrag, ep, out, n_cells, stream);
+    if (folded && layer == 5) return launch_cfg<CfgL6F>(in, wfrag, ep, out, n_cells, stream);
     switch (layer) {
         case 0: return launch_cfg<CfgL1>(in, wfrag, ep, out, n_cells, stream);
         case 1: return launch_cfg<CfgL2>(in, wfrag, ep, out, n_cells, stream);
@@ -435,6 +528,39 @@ hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, f
         case 6: return launch_cfg<CfgD7>(dz, wfrag_t, nullptr, dx, n_cells, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Folded-upsample fragments (ConvCfg FOLD): effective 2x2 kernels per output phase (a,b),
+//   W_eff[a][b][ry][rx] = sum of W[dy][dx] over taps with ((a+dy)>>1)+1 == a+ry and ((b+dx)>>1)+1 == b+rx
+// (dy,dx in -1..1), summed in fp32 in (dy,dx) order.  Layout: cout 32 (two waves per slice, one
+// per row phase): [slice][a][(b*4 + tap)*KQ + q][j][lane]; cout 64: [slice][((a*2+b)*4 + tap)*KQ + q][j][lane].
+size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* dst)
+{
+    const int nsl_n = cout / 16, nmg = 4 / nsl_n, kq_n = cin / 16, gk = 4 * kq_n;
+    const int phw = (nmg == 2) ? 2 : 4, nb = phw * gk * 4;
+    const size_t total = (size_t)nsl_n * (nmg == 2 ? 2 : 1) * nb * 64;
+    if (!dst) return total;
+    for (int nsl = 0; nsl < nsl_n; ++nsl)
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int tap = 0; tap < 4; ++tap)
+                    for (int q = 0; q < kq_n; ++q)
+                        for (int j = 0; j < 4; ++j)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int li = lane & 15, kq = lane >> 4, ry = tap >> 1, rx = tap & 1;
+                                const int ci = 16 * q + 4 * kq + j, co = nsl * 16 + li;
+                                float sum = 0.0f;
+                                for (int dy = -1; dy <= 1; ++dy)
+                                    for (int dx = -1; dx <= 1; ++dx)
+                                        if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx)
+                                            sum += hwio[((size_t)((dy + 1) * 3 + (dx + 1)) * cin + ci) * cout + co];
+                                const int g = tap * kq_n + q;
+                                size_t idx;
+                                if (nmg == 2) idx = ((((size_t)nsl * 2 + a) * nb) + ((size_t)(b * gk + g) * 4 + j)) * 64 + lane;
+                                else idx = (((size_t)nsl * nb) + ((size_t)((a * 2 + b) * gk + g) * 4 + j)) * 64 + lane;
+                                dst[idx] = sum;
+                            }
+    return total;
 }
 
 // wfrag[nsl][s][lane]: the value lane (li = lane & 15, kq = lane >> 4) feeds as B[k = kq][n = li]
