@@ -67,7 +67,10 @@ struct ConvCfg {
     static constexpr int WS = UPS ? W / 2 : W;
     static constexpr int R = UPS ? SR / 2 + 2 : SR + 2;     // staged rows (incl. halo)
     static constexpr int WP = WS + 2;                // staged cols (incl. halo)
-    static constexpr int PS = (CIN == 1) ? 1 : CIN + 4;     // floats per staged pixel
+    // floats per staged pixel: +8 makes the pixel stride 2*odd 16-B slots, so the 16 pixels x 2 channel
+    // quads of each ds_read_b128 lane group land on 16 distinct slots (+4 left a 2-way conflict on
+    // every read: PMC SQ_LDS_BANK_CONFLICT was 48 % of SQ_LDS_IDX_ACTIVE)
+    static constexpr int PS = (CIN == 1) ? 1 : CIN + 8;
     static constexpr int STRIP_BYTES = (R * WP * PS * 4 + 15) / 16 * 16;
     static constexpr int LDS_BYTES = STRIP_BYTES * (MODE == STAGE_DB ? 2 : 1);
     static constexpr int NSTRIP = H / SR;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
 //                       H   W  CIN COUT EPI          UPS    SR WPS MODE
 // inference (CAE_improved_modeltrain.py:191-214 with BatchNormalization in inference mode)
 using CfgL1 = ConvCfg<64, 64,  1, 32, EPI_BN_POOL, false, 16, 4, STAGE_PF>;   // :191-193
-using CfgL2 = ConvCfg<32, 32, 32, 64, EPI_BN_POOL, false,  4, 3, STAGE_PF>;   // :195-197
+using CfgL2 = ConvCfg<32, 32, 32, 64, EPI_BN_POOL, false,  8, 2, STAGE_PF>;   // :195-197
 using CfgL3 = ConvCfg<16, 16, 64, 32, EPI_BN_POOL, false,  4, 2, STAGE_DB>;   // :199-201 -> encoded 8x8x32
 using CfgL4 = ConvCfg< 8,  8, 32, 32, EPI_BN,      false,  8, 3, STAGE_PF>;   // :204-205
 using CfgL5 = ConvCfg<16, 16, 32, 64, EPI_BN,      true,  16, 3, STAGE_PF>;   // :206-209 (reads up(a4))

@@ -34,28 +34,44 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
     float (*red)[4] = (float (*)[4])(smem + C7_LDS);  // 2 x 4 wave sums, after the strip
     const int tid = threadIdx.x;
     const long total = n_cells * C7_NSTRIP;
+    // The kernel is HBM-bound (it streams a6 once, 172 KB/cell with the row halo), so the strip of
+    // item i+1 is loaded into registers before the arithmetic of item i and written to LDS after
+    // it: loads stay in flight the whole time instead of only between items.
+    constexpr int C4 = C7_CIN / 4;
+    constexpr int TOT = C7_R * C7_WP * C4;
+    constexpr int NLD = (TOT + 255) / 256;
+    f32x4 stg[NLD];
+    auto issue = [&](long item) {
+        const long cell = item / C7_NSTRIP;
+        const int y0 = (int)(item % C7_NSTRIP) * C7_SR;
+        const float* src = a6 + (size_t)cell * C7_HS * C7_WS * C7_CIN;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + 256 * k;
+            const int pix = idx / C4, c4 = idx % C4;
+            const int r = pix / C7_WP, c = pix % C7_WP;
+            const int sy = y0 - 1 + r, sx = c - 1;
+            stg[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx < TOT && sy >= 0 && sy < C7_HS && sx >= 0 && sx < C7_WS)
+                stg[k] = *(const f32x4*)(src + ((size_t)sy * C7_WS + sx) * C7_CIN + c4 * 4);
+        }
+    };
+    if ((long)blockIdx.x < total) issue(blockIdx.x);
     for (long item = blockIdx.x; item < total; item += gridDim.x) {
         const long cell = item / C7_NSTRIP;
         const int strip = (int)(item % C7_NSTRIP);
         const int y0 = strip * C7_SR;  // first a6 row of the strip
 
-        // stage a6 rows y0-1 .. y0+SR with zero halo
-        {
-            constexpr int C4 = C7_CIN / 4;
-            constexpr int TOT = C7_R * C7_WP * C4;
-            const float* src = a6 + (size_t)cell * C7_HS * C7_WS * C7_CIN;
-#pragma unroll 4
-            for (int idx = tid; idx < TOT; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < TOT) {
                 const int pix = idx / C4, c4 = idx % C4;
-                const int r = pix / C7_WP, c = pix % C7_WP;
-                const int sy = y0 - 1 + r, sx = c - 1;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (sy >= 0 && sy < C7_HS && sx >= 0 && sx < C7_WS)
-                    v = *(const f32x4*)(src + ((size_t)sy * C7_WS + sx) * C7_CIN + c4 * 4);
-                *(f32x4*)(smem + (pix * C7_PS + c4 * 4) * 4) = v;
+                *(f32x4*)(smem + (pix * C7_PS + c4 * 4) * 4) = stg[k];
             }
         }
         __syncthreads();
+        if (item + gridDim.x < total) issue(item + gridDim.x);
 
         const int ly = tid >> 5, lx = tid & 31;  // a6 pixel (y0 + ly, lx)
         float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
