@@ -3,7 +3,7 @@
 // on the exact-fp32 MFMA: 16 multiplies per 2x2 output tile and channel pair instead of 36, i.e.
 // 4/9 of the multiply-adds of the direct form (conv2 is 45 % of the path's direct MACs).
 //
-//   V = B^T d B      input transform of each 4x4 patch d (stride 2), VALU, into LDS
+//   V = B^T d B      input transform of each 4x4 patch d (stride 2), VALU, in registers
 //   M_xi = V_xi U_xi  16 independent [tiles x cin] x [cin x cout] products, xi = 0..15   (MFMA)
 //   Y = A^T M A      output transform, 2x2 outputs per tile, VALU in the MFMA epilogue
 // with U = G g G^T pre-computed on the host (in double, rounded once).  The 2x2 output tile IS
@@ -13,8 +13,8 @@
 //
 // Work split: a workgroup = 4 waves = the 4 16-channel output slices; a work item = one cell x 4
 // conv rows = 2 rows of 16 tiles.  Each wave keeps its slice of U (16 xi x 8 K steps = 128 VGPRs)
-// resident and accumulates all 16 xi of a 16-tile row in registers (16 accumulators), so the
-// output transform needs no cross-lane traffic.
+// resident and walks V one column at a time (4 accumulators), folding each column into the
+// first half of the output transform, so neither transform needs cross-lane traffic.
 #include "common.hpp"
 
 namespace cs {
@@ -23,24 +23,46 @@ namespace {
 
 constexpr int WN_H = 32, WN_W = 32, WN_CIN = 32, WN_COUT = 64;
 constexpr int WN_SR = 4;                                   // conv rows per item (2 tile rows)
+constexpr int WN_NTR = WN_SR / 2;                          // tile rows per item
 constexpr int WN_R = WN_SR + 2, WN_WP = WN_W + 2;          // staged rows / cols incl. halo
-constexpr int WN_PS = WN_CIN + 8;                          // padded pixel stride (floats), conflict-free b128 reads
-constexpr int WN_STRIP = WN_R * WN_WP * WN_PS * 4;         // 32,640 B
-constexpr int WN_TILES = WN_W / 2;                         // 16 tiles per tile row
-constexpr int WN_VS = WN_CIN + 8;                          // padded tile stride of V (floats)
-constexpr int WN_V = 16 * WN_TILES * WN_VS * 4;            // 40,960 B
-constexpr int WN_LDS = WN_STRIP + WN_V;
+// padded pixel stride (floats): tiles step 2 pixels, so an ODD number of 16-B slots per pixel makes
+// the 16 tiles x 2 channel quads of a ds_read_b128 lane group land on 16 distinct slots
+constexpr int WN_PS = WN_CIN + 4;
+constexpr int WN_STRIP = WN_R * WN_WP * WN_PS * 4;         // 29,376 B, double buffered
+constexpr int WN_LDS = 2 * WN_STRIP;
 constexpr int WN_NSTRIP = WN_H / WN_SR;                    // 8 items per cell
 constexpr int WN_NB = 16 * 8;                              // B registers: 16 xi x (cin / 4) K steps
+constexpr int WN_C4 = WN_CIN / 4, WN_TOT = WN_R * WN_WP * WN_C4;
+constexpr int WN_NLD = (WN_TOT + 255) / 256;               // per-thread 16-B loads per strip (7)
+constexpr int WN_LPP = (WN_NLD + WN_NTR - 1) / WN_NTR;     // per tile-row iteration (4)
 
+__device__ __forceinline__ f32x4 wn_load(const float* __restrict__ in, long cell, int y0, int idx)
+{
+    const float* src = in + (size_t)cell * WN_H * WN_W * WN_CIN;
+    const int pix = idx / WN_C4, c4 = idx % WN_C4;
+    const int r = pix / WN_WP, c = pix % WN_WP;
+    const int sy = y0 - 1 + r, sx = c - 1;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (idx < WN_TOT && sy >= 0 && sy < WN_H && sx >= 0 && sx < WN_W)
+        v = *(const f32x4*)(src + ((size_t)sy * WN_W + sx) * WN_CIN + c4 * 4);
+    return v;
+}
+__device__ __forceinline__ void wn_store(float* strip, int idx, const f32x4& v)
+{
+    if (idx < WN_TOT) *(f32x4*)(strip + (idx / WN_C4) * WN_PS + (idx % WN_C4) * 4) = v;
+}
+
+// Every wave derives its own A operands: lane (tile, kq) reads the 4x4 patch of ITS tile for ITS
+// four channels and applies B^T d B in registers, one output column of V at a time, feeding the
+// MFMAs directly.  The four output-slice waves repeat the same transform (the VALU is otherwise
+// idle) but no transformed tensor goes through LDS and no barrier separates transform and product:
+// one barrier per item (strip double buffer) is all that is left.
 __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
     const float* __restrict__ in /* p1 [n][32][32][32] */, const float* __restrict__ ufrag,
     const float* __restrict__ ep /* [3][64] bias, bn scale, bn shift */, float* __restrict__ out /* p2 [n][16][16][64] */,
     long n_cells)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* strip = (float*)smem;
-    float* V = (float*)(smem + WN_STRIP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int nsl = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output-channel slice
     const int li = lane & 15, kq = lane >> 4;
@@ -51,111 +73,73 @@ __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
     const int co = nsl * 16 + li;
     const float bias = ep[co], bns = ep[WN_COUT + co], bnt = ep[2 * WN_COUT + co];
 
-    // input-transform role of this thread: tile, channel quad, half of the xi rows
-    const int t_tile = tid & 15, t_cq = (tid >> 4) & 7, t_half = tid >> 7;
-
-    // strip staging, software pipelined: item i+1's loads are issued before item i's second
-    // tile row and written to LDS when item i+1 begins (see conv_mfma.hip STAGE_PF)
-    constexpr int C4 = WN_CIN / 4, TOT = WN_R * WN_WP * C4, NLD = (TOT + 255) / 256;
-    f32x4 stg[NLD];
-    auto issue = [&](long item) {
-        const long cell = item / WN_NSTRIP;
-        const int y0 = (int)(item % WN_NSTRIP) * WN_SR;
-        const float* src = in + (size_t)cell * WN_H * WN_W * WN_CIN;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + 256 * k;
-            const int pix = idx / C4, c4 = idx % C4;
-            const int r = pix / WN_WP, c = pix % WN_WP;
-            const int sy = y0 - 1 + r, sx = c - 1;
-            stg[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (idx < TOT && sy >= 0 && sy < WN_H && sx >= 0 && sx < WN_W)
-                stg[k] = *(const f32x4*)(src + ((size_t)sy * WN_W + sx) * WN_CIN + c4 * 4);
-        }
-    };
     const long total = n_cells * WN_NSTRIP;
-    if ((long)blockIdx.x < total) issue(blockIdx.x);
-    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+    const long first = blockIdx.x;
+    if (first >= total) return;
+#pragma unroll 4
+    for (int idx = tid; idx < WN_TOT; idx += 256)
+        wn_store((float*)smem, idx, wn_load(in, first / WN_NSTRIP, (int)(first % WN_NSTRIP) * WN_SR, idx));
+    __syncthreads();
+
+    int buf = 0;
+    for (long item = first; item < total; item += gridDim.x) {
         const long cell = item / WN_NSTRIP;
         const int y0 = (int)(item % WN_NSTRIP) * WN_SR;
-        // ---- conv rows y0-1 .. y0+4 of p1 with a zero halo: registers -> LDS ------------------
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < TOT) {
-                const int pix = idx / C4, c4 = idx % C4;
-                *(f32x4*)(strip + pix * WN_PS + c4 * 4) = stg[k];
-            }
-        }
-        __syncthreads();
+        const long nitem = item + gridDim.x;
+        const bool has_next = nitem < total;
+        const long ncell = nitem / WN_NSTRIP;
+        const int ny0 = (int)(nitem % WN_NSTRIP) * WN_SR;
+        const float* strip = (const float*)(smem + buf * WN_STRIP);
+        float* nstrip = (float*)(smem + (buf ^ 1) * WN_STRIP);
 
-        for (int tr = 0; tr < WN_SR / 2; ++tr) {
-            // ---- input transform V = B^T d B of the 16 tiles of tile row tr ------------------
-            // tile (tr, t_tile): patch rows 2tr .. 2tr+3, cols 2t .. 2t+3 of the staged strip
-            {
-                const float* d0 = strip + ((2 * tr) * WN_WP + 2 * t_tile) * WN_PS + t_cq * 4;
-                // this thread makes xi rows {0,1} (t_half = 0: needs patch rows 0,1,2) or {2,3} (rows 1,2,3)
-                f32x4 tA[4], tB[4];
+        for (int tr = 0; tr < WN_NTR; ++tr) {
+            f32x4 stg[WN_LPP];
+            if (has_next) {   // this iteration's slice of the next strip: loads now, LDS writes at the bottom
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 r1 = *(const f32x4*)(d0 + (1 * WN_WP + c) * WN_PS);
-                    const f32x4 r2 = *(const f32x4*)(d0 + (2 * WN_WP + c) * WN_PS);
-                    if (t_half == 0) {
-                        const f32x4 r0 = *(const f32x4*)(d0 + (0 * WN_WP + c) * WN_PS);
-                        tA[c] = r0 - r2;      // B^T row 0
-                        tB[c] = r1 + r2;      // B^T row 1
-                    } else {
-                        const f32x4 r3 = *(const f32x4*)(d0 + (3 * WN_WP + c) * WN_PS);
-                        tA[c] = r2 - r1;      // B^T row 2
-                        tB[c] = r1 - r3;      // B^T row 3
+                for (int j = 0; j < WN_LPP; ++j) stg[j] = wn_load(in, ncell, ny0, tid + 256 * (tr * WN_LPP + j));
+            }
+            // patch of tile li: strip rows 2tr .. 2tr+3, cols 2li .. 2li+3; this lane's channels 16q + 4kq ..
+            const float* d0 = strip + ((2 * tr) * WN_WP + 2 * li) * WN_PS + 4 * kq;
+            float s0[4][4], s1[4][4];   // [column c of M][tile register r]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // V[:, c] = B^T (d B[:, c]):  d B[:, c] combines patch columns (ca, cb) with sign sg
+                constexpr int CA[4] = {0, 1, 2, 1}, CB[4] = {2, 2, 1, 3};
+                constexpr float SG[4] = {-1.0f, 1.0f, -1.0f, -1.0f};
+                f32x4 acc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // keep the scheduler from hoisting every step's patch loads to the top (register spills)
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 da = *(const f32x4*)(d0 + (i * WN_WP + CA[c]) * WN_PS + 16 * q);
+                        const f32x4 db = *(const f32x4*)(d0 + (i * WN_WP + CB[c]) * WN_PS + 16 * q);
+                        w[i] = da + SG[c] * db;
                     }
+                    const f32x4 v[4] = {w[0] - w[2], w[1] + w[2], w[2] - w[1], w[1] - w[3]};   // xi = 4 r + c
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[r][j], B[(4 * r + c) * 8 + 4 * q + j], acc[r], 0, 0, 0);
                 }
-                float* vo = V + (size_t)t_tile * WN_VS + t_cq * 4;
-                const int xa = (2 * t_half) * 4, xb = (2 * t_half + 1) * 4;   // first xi of the two rows
-                auto put = [&](int xi, const f32x4& v) { *(f32x4*)(vo + (size_t)xi * WN_TILES * WN_VS) = v; };
-                put(xa + 0, tA[0] - tA[2]); put(xa + 1, tA[1] + tA[2]); put(xa + 2, tA[2] - tA[1]); put(xa + 3, tA[1] - tA[3]);
-                put(xb + 0, tB[0] - tB[2]); put(xb + 1, tB[1] + tB[2]); put(xb + 2, tB[2] - tB[1]); put(xb + 3, tB[1] - tB[3]);
-            }
-            __syncthreads();
-            if (tr == WN_SR / 2 - 1 && item + gridDim.x < total) issue(item + gridDim.x);   // in flight during the last GEMM
-
-            // ---- 16 products M_xi[tile][cout] = V_xi[tile][cin] U_xi[cin][cout] -----------------
-            f32x4 acc[16];
+                // first half of the output transform: s = A^T M  (rows of M live in acc[0..3])
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) acc[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* va = V + (size_t)li * WN_VS + kq * 4;
-#pragma unroll
-            for (int xp = 0; xp < 8; ++xp) {   // two xi at a time: two independent accumulation chains
-                const int x0 = 2 * xp, x1 = 2 * xp + 1;
-                const f32x4 a00 = *(const f32x4*)(va + (size_t)x0 * WN_TILES * WN_VS);
-                const f32x4 a01 = *(const f32x4*)(va + (size_t)x0 * WN_TILES * WN_VS + 16);
-                const f32x4 a10 = *(const f32x4*)(va + (size_t)x1 * WN_TILES * WN_VS);
-                const f32x4 a11 = *(const f32x4*)(va + (size_t)x1 * WN_TILES * WN_VS + 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[j], B[x0 * 8 + j], acc[x0], 0, 0, 0);
-                    acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[j], B[x1 * 8 + j], acc[x1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[j], B[x0 * 8 + 4 + j], acc[x0], 0, 0, 0);
-                    acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[j], B[x1 * 8 + 4 + j], acc[x1], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    s0[c][r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+                    s1[c][r] = (acc[1][r] - acc[2][r]) - acc[3][r];
                 }
             }
-
-            // ---- output transform Y = A^T M A, bias -> relu -> BN -> 2x2 max, per tile ---------
-            // D layout: lane holds cout li, register r <-> tile 4*kq + r
+            // second half Y = s A, then bias -> relu -> BN -> 2x2 max per tile (register r <-> tile 4 kq + r)
             float res[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s0[4], s1[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0[c] = (acc[0 * 4 + c][r] + acc[1 * 4 + c][r]) + acc[2 * 4 + c][r];
-                    s1[c] = (acc[1 * 4 + c][r] - acc[2 * 4 + c][r]) - acc[3 * 4 + c][r];
-                }
-                const float y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
-                const float y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+                const float y00 = (s0[0][r] + s0[1][r]) + s0[2][r], y01 = (s0[1][r] - s0[2][r]) - s0[3][r];
+                const float y10 = (s1[0][r] + s1[1][r]) + s1[2][r], y11 = (s1[1][r] - s1[2][r]) - s1[3][r];
                 auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
                 res[r] = fmaxf(fmaxf(post(y00), post(y01)), fmaxf(post(y10), post(y11)));
             }
@@ -163,8 +147,13 @@ __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
             float* o = out + (((size_t)cell * (WN_H / 2) + ty) * (WN_W / 2) + 4 * kq) * WN_COUT + co;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(size_t)r * WN_COUT] = res[r];
-            __syncthreads();   // V is rewritten by the next tile row / the strip by the next item
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < WN_LPP; ++j) wn_store(nstrip, tid + 256 * (tr * WN_LPP + j), stg[j]);
+            }
         }
+        __syncthreads();   // this strip fully read; the next strip complete in the other buffer
+        buf ^= 1;
     }
 }
 
