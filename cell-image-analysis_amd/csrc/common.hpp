@@ -55,16 +55,19 @@ hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag,
 hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, float* dx, int64_t n_cells,
                              hipStream_t stream);
 hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s);
-hipError_t launch_bn_apply(const float* r, const float* part, int G, int C, const float* gamma, const float* beta,
-                           float eps, float momentum, float* mov_mean, float* mov_var, float* stats, float* a,
+hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, float momentum, float* mov_mean,
+                                 float* mov_var, float* stats, hipStream_t s);
+hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const float* beta, const float* stats, float* a,
                            long N, int H, int W, int pool, hipStream_t s);
 hipError_t launch_loss_dz(const float* out, const float* y, long total, float* dz, float* dzsum_part, int* G, hipStream_t s);
 hipError_t launch_loss_scalar(const float* errpart, long nparts, long nelem, float* out2, hipStream_t s);
 hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
                                 long N, int H, int W, int C, int pool, float* part, int* G, hipStream_t s);
+hipError_t launch_bn_bwd_final(const float* part, int G, int C, double nred, float* sums, float* dgamma, float* dbeta,
+                               hipStream_t s);
 hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
-                            const float* part, int G, long N, int H, int W, int C, int pool, float* dz,
-                            float* dzsum_part, int* Gz, float* dgamma, float* dbeta, hipStream_t s);
+                            const float* sums, long N, int H, int W, int C, int pool, float* dz, float* dzsum_part,
+                            int* Gz, hipStream_t s);
 hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
                         hipStream_t s);
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int c = tid % C, lane = tid / C, L = 256 / C;
     const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
     float s = 0.0f;
+#pragma unroll 8
     for (long p = p0 + lane; p < p1; p += L) s += r[p * C + c];
     red[tid] = s;
     __syncthreads();
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     __syncthreads();
     const float mu = meanc[c];
     float m2 = 0.0f;
+#pragma unroll 8
     for (long p = p0 + lane; p < p1; p += L) { const float d = r[p * C + c] - mu; m2 = fmaf(d, d, m2); }
     __syncthreads();
     red[tid] = m2;
@@ -48,11 +50,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__device__ __forceinline__ void bn_merge(const float* __restrict__ part, int G, int C, int c,
-                                         double& mean, double& var)
+// One workgroup merges the G partials of a layer in a fixed two-level order (8 groups of
+// consecutive partials per channel, then the 8 group results), publishes {mean, inv} for
+// bn_apply / the backward pass and updates the moving statistics
+// (moving = moving*momentum + batch*(1-momentum)).  Merging inside every workgroup of
+// bn_apply cost 20 us per layer (G dependent L2 round trips on each CU).
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part, int G, int C, float eps,
+                                                             float momentum, float* __restrict__ mov_mean,
+                                                             float* __restrict__ mov_var, float* __restrict__ stats)
 {
+    __shared__ double sn[256], smu[256], sM2[256];
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C, NG = 256 / C;
+    const int g0 = (G * grp) / NG, g1 = (G * (grp + 1)) / NG;
     double n = 0.0, mu = 0.0, M2 = 0.0;
-    for (int g = 0; g < G; ++g) {
+#pragma unroll 4
+    for (int g = g0; g < g1; ++g) {
         const float* o = part + (size_t)g * 3 * C;
         const double nb = o[c], mb = o[C + c], M2b = o[2 * C + c];
         const double tot = n + nb, delta = mb - mu;
@@ -60,47 +72,51 @@ __device__ __forceinline__ void bn_merge(const float* __restrict__ part, int G, 
         M2 += M2b + delta * delta * (n * nb / tot);
         n = tot;
     }
-    mean = mu;
-    var = M2 / n;   // biased, as Keras normalises with (and Keras 3 averages) the batch variance
+    sn[tid] = n; smu[tid] = mu; sM2[tid] = M2;
+    __syncthreads();
+    if (tid < C) {
+        n = 0.0; mu = 0.0; M2 = 0.0;
+        for (int k = 0; k < NG; ++k) {
+            const double nb = sn[k * C + tid], mb = smu[k * C + tid], M2b = sM2[k * C + tid];
+            if (nb > 0.0) {
+                const double tot = n + nb, delta = mb - mu;
+                mu += delta * (nb / tot);
+                M2 += M2b + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+        }
+        const float fm = (float)mu, fv = (float)(M2 / n);   // biased variance, as Keras normalises with
+        stats[tid] = fm;
+        stats[C + tid] = 1.0f / sqrtf(fv + eps);
+        mov_mean[tid] = mov_mean[tid] * momentum + fm * (1.0f - momentum);
+        mov_var[tid] = mov_var[tid] * momentum + fv * (1.0f - momentum);
+    }
 }
 
 // y = gamma*(r-mean)*inv + beta, then 2x2 max-pool (encoder) or identity (decoder).
-// Block 0 also publishes {mean, inv} for the backward pass and updates the moving statistics
-// (moving = moving*momentum + batch*(1-momentum)).
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const float* __restrict__ r, const float* __restrict__ part, int G, int C,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-    float* __restrict__ mov_mean, float* __restrict__ mov_var, float* __restrict__ stats /*[2][C]*/,
-    float* __restrict__ a, long N, int H, int W, int pool)
+    const float* __restrict__ r, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats /*[2][C]*/, float* __restrict__ a, long N, int H, int W, int pool)
 {
     __shared__ float sm[64], si[64], sg[64], sb[64];
     const int tid = threadIdx.x;
-    if (tid < C) {
-        double mean, var;
-        bn_merge(part, G, C, tid, mean, var);
-        const float fm = (float)mean, fv = (float)var;
-        const float inv = 1.0f / sqrtf(fv + eps);
-        sm[tid] = fm; si[tid] = inv; sg[tid] = gamma[tid]; sb[tid] = beta[tid];
-        if (blockIdx.x == 0) {
-            stats[tid] = fm;
-            stats[C + tid] = inv;
-            mov_mean[tid] = mov_mean[tid] * momentum + fm * (1.0f - momentum);
-            mov_var[tid] = mov_var[tid] * momentum + fv * (1.0f - momentum);
-        }
-    }
+    if (tid < C) { sm[tid] = stats[tid]; si[tid] = stats[C + tid]; sg[tid] = gamma[tid]; sb[tid] = beta[tid]; }
     __syncthreads();
-    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
-    const long total = N * Ho * Wo * C;
-    for (long o = (long)blockIdx.x * 256 + tid; o < total; o += (long)gridDim.x * 256) {
-        const int c = (int)(o % C);
-        const long pix = o / C;
+    // H, W, C are powers of two and batch*H*W*C < 2^31: 32-bit shift/mask indexing (64-bit integer
+    // division costs far more than the arithmetic of these kernels)
+    const int lC = __ffs(C) - 1, lW = __ffs(W) - 1, lH = __ffs(H) - 1;
+    const int lWo = pool ? lW - 1 : lW, lHo = pool ? lH - 1 : lH;
+    const int total = (int)(N << (lHo + lWo + lC));
+#pragma unroll 4
+    for (int o = blockIdx.x * 256 + tid; o < total; o += gridDim.x * 256) {
+        const int c = o & (C - 1);
+        const int pix = o >> lC;
         const float g = sg[c] * si[c], b = sb[c] - sm[c] * g;   // y = r*g + b
         if (pool) {
-            const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho);
-            const long n = pix / ((long)Wo * Ho);
-            const float* p = r + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+            const int xo = pix & ((1 << lWo) - 1), yo = (pix >> lWo) & ((1 << lHo) - 1), n = pix >> (lWo + lHo);
+            const float* p = r + ((((size_t)n << lH) + 2 * yo) << lW) * C + (size_t)(2 * xo) * C + c;
             const float y00 = fmaf(p[0], g, b), y01 = fmaf(p[C], g, b);
-            const float y10 = fmaf(p[(long)W * C], g, b), y11 = fmaf(p[(long)W * C + C], g, b);
+            const float y10 = fmaf(p[(size_t)W * C], g, b), y11 = fmaf(p[(size_t)W * C + C], g, b);
             a[o] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
         } else {
             a[o] = fmaf(r[o], g, b);
@@ -117,6 +133,7 @@ __global__ __launch_bounds__(256) void loss_dz_kernel(const float* __restrict__ 
     __shared__ float red[4];
     const float k = 2.0f / (float)total;
     float s = 0.0f;
+#pragma unroll 4
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const float o = out[i];
         const float d = k * (o - y[i]) * o * (1.0f - o);
@@ -146,11 +163,11 @@ __global__ void loss_scalar_kernel(const float* __restrict__ errpart, long npart
 // at full resolution for decoder layers.
 struct Win { float dy[4]; float xh[4]; float r[4]; };
 
-__device__ __forceinline__ void window(const float* __restrict__ da, const float* __restrict__ r, long n, int yo,
+__device__ __forceinline__ void window(const float* __restrict__ da, const float* __restrict__ r, int n, int yo,
                                        int xo, int c, int H, int W, int C, float mean, float inv, float gam,
                                        float bet, Win& w)
 {
-    const float* p = r + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+    const float* p = r + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
     w.r[0] = p[0]; w.r[1] = p[C]; w.r[2] = p[(long)W * C]; w.r[3] = p[(long)W * C + C];
     float best = -INFINITY;
     int arg = 0;
@@ -160,7 +177,7 @@ __device__ __forceinline__ void window(const float* __restrict__ da, const float
         const float y = fmaf(w.xh[j], gam, bet);
         if (y > best) { best = y; arg = j; }
     }
-    const float g = da[((n * (H / 2) + yo) * (W / 2) + xo) * C + c];
+    const float g = da[(((size_t)n * (H / 2) + yo) * (W / 2) + xo) * C + c];
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.dy[j] = (j == arg) ? g : 0.0f;
 }
@@ -176,11 +193,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
     double s0 = 0.0, s1 = 0.0;
     if (pool) {
-        const long P = N * (H / 2) * (W / 2);
-        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
-        for (long p = p0 + lane; p < p1; p += L) {
-            const int xo = (int)(p % (W / 2)), yo = (int)((p / (W / 2)) % (H / 2));
-            const long n = p / ((long)(W / 2) * (H / 2));
+        const int lWo = __ffs(W) - 2, lHo = __ffs(H) - 2;
+        const int P = (int)(N << (lWo + lHo));
+        const int p0 = (int)(((long)P * blockIdx.x) / gridDim.x), p1 = (int)(((long)P * (blockIdx.x + 1)) / gridDim.x);
+#pragma unroll 2
+        for (int p = p0 + lane; p < p1; p += L) {
+            const int xo = p & ((1 << lWo) - 1), yo = (p >> lWo) & ((1 << lHo) - 1), n = p >> (lWo + lHo);
             Win w;
             window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
 #pragma unroll
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     } else {
         const long P = N * H * W;
         const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+#pragma unroll 8
         for (long p = p0 + lane; p < p1; p += L) {
             const float dy = da[p * C + c];
             const float xh = (r[p * C + c] - mean) * inv;
@@ -206,39 +225,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+// Sums the per-workgroup {sum dy, sum dy*xhat} in a fixed two-level order; writes the means used
+// by bn_bwd_dz and the parameter gradients dbeta = sum dy, dgamma = sum dy*xhat.
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int G, int C, double nred,
+                                                           float* __restrict__ sums /*[2][C] means*/,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ double s0[256], s1[256];
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C, NG = 256 / C;
+    const int g0 = (G * grp) / NG, g1 = (G * (grp + 1)) / NG;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll 4
+    for (int g = g0; g < g1; ++g) { t0 += part[(size_t)g * 2 * C + c]; t1 += part[(size_t)g * 2 * C + C + c]; }
+    s0[tid] = t0; s1[tid] = t1;
+    __syncthreads();
+    if (tid < C) {
+        t0 = 0.0; t1 = 0.0;
+        for (int k = 0; k < NG; ++k) { t0 += s0[k * C + tid]; t1 += s1[k * C + tid]; }
+        sums[tid] = (float)(t0 / nred);
+        sums[C + tid] = (float)(t1 / nred);
+        dbeta[tid] = (float)t0;
+        dgamma[tid] = (float)t1;
+    }
+}
+
 // dz = relu'(r) * gamma*inv * (dy - mean(dy) - xhat*mean(dy*xhat)); also sum(dz) per channel
 // (the conv bias gradient) and, from block 0, dgamma = sum(dy*xhat), dbeta = sum(dy).
 __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(
     const float* __restrict__ da, const float* __restrict__ r, const float* __restrict__ stats,
-    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, int G,
-    long N, int H, int W, int C, int pool, float* __restrict__ dz, float* __restrict__ dzsum_part /*[Gz][C]*/,
-    float* __restrict__ dgamma, float* __restrict__ dbeta)
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums /*[2][C]*/,
+    long N, int H, int W, int C, int pool, float* __restrict__ dz, float* __restrict__ dzsum_part /*[Gz][C]*/)
 {
-    __shared__ float sdy[64], sdx[64];
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    if (tid < C) {
-        double t0 = 0.0, t1 = 0.0;
-        for (int g = 0; g < G; ++g) { t0 += part[(size_t)g * 2 * C + tid]; t1 += part[(size_t)g * 2 * C + C + tid]; }
-        const double nred = (double)N * H * W;
-        sdy[tid] = (float)(t0 / nred);
-        sdx[tid] = (float)(t1 / nred);
-        if (blockIdx.x == 0) { dbeta[tid] = (float)t0; dgamma[tid] = (float)t1; }
-    }
-    __syncthreads();
     const int c = tid % C, lane = tid / C, L = 256 / C;
     const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
-    const float k = gam * inv, mdy = sdy[c], mdx = sdx[c];
+    const float k = gam * inv, mdy = sums[c], mdx = sums[C + c];
     double s = 0.0;
     if (pool) {
-        const long P = N * (H / 2) * (W / 2);
-        const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
-        for (long p = p0 + lane; p < p1; p += L) {
-            const int xo = (int)(p % (W / 2)), yo = (int)((p / (W / 2)) % (H / 2));
-            const long n = p / ((long)(W / 2) * (H / 2));
+        const int lWo = __ffs(W) - 2, lHo = __ffs(H) - 2;
+        const int P = (int)(N << (lWo + lHo));
+        const int p0 = (int)(((long)P * blockIdx.x) / gridDim.x), p1 = (int)(((long)P * (blockIdx.x + 1)) / gridDim.x);
+#pragma unroll 2
+        for (int p = p0 + lane; p < p1; p += L) {
+            const int xo = p & ((1 << lWo) - 1), yo = (p >> lWo) & ((1 << lHo) - 1), n = p >> (lWo + lHo);
             Win w;
             window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
-            float* o = dz + ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+            float* o = dz + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
             const long offs[4] = {0, C, (long)W * C, (long)W * C + C};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -251,6 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(
     } else {
         const long P = N * H * W;
         const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
+#pragma unroll 8
         for (long p = p0 + lane; p < p1; p += L) {
             const float rv = r[p * C + c];
             const float xh = (rv - mean) * inv;
@@ -377,11 +411,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict
 }
 
 //                    H   W  CIN COUT UPS    SR
-using WgL2 = WgCfg<32, 32, 32, 64, false,  8>;
-using WgL3 = WgCfg<16, 16, 64, 32, false,  8>;
-using WgL4 = WgCfg< 8,  8, 32, 32, false,  8>;
-using WgL5 = WgCfg<16, 16, 32, 64, true,  16>;
-using WgL6 = WgCfg<32, 32, 64, 32, true,   8>;
+using WgL2 = WgCfg<32, 32, 32, 64, false,  4>;
+using WgL3 = WgCfg<16, 16, 64, 32, false,  4>;
+using WgL4 = WgCfg< 8,  8, 32, 32, false,  4>;
+using WgL5 = WgCfg<16, 16, 32, 64, true,   4>;
+using WgL6 = WgCfg<32, 32, 64, 32, true,   4>;
 
 template <class C>
 hipError_t launch_wg(const float* xin, const float* dz, float* part, int64_t n_cells, int max_parts, int* nparts,
@@ -499,6 +533,7 @@ __global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndes
         if (i < base + D.len) {
             const long e = i - base;
             float s = 0.0f;
+#pragma unroll 8
             for (int p = 0; p < D.nparts; ++p) s += D.src[(size_t)p * D.stride + e];
             flat_grad[D.dst + e] = s;
             return;
@@ -581,14 +616,20 @@ hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, h
     return hipGetLastError();
 }
 
-hipError_t launch_bn_apply(const float* r, const float* part, int G, int C, const float* gamma, const float* beta,
-                           float eps, float momentum, float* mov_mean, float* mov_var, float* stats, float* a,
+hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, float momentum, float* mov_mean,
+                                 float* mov_var, float* stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, s, part, G, C, eps, momentum, mov_mean, mov_var, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const float* beta, const float* stats, float* a,
                            long N, int H, int W, int pool, hipStream_t s)
 {
     const long total = N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
-    long g = (total + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, r, part, G, C, gamma, beta, eps, momentum,
-                       mov_mean, mov_var, stats, a, N, H, W, pool);
+    if (total >= (1L << 31)) return hipErrorInvalidValue;
+    long g = (total + 1023) / 1024; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, r, C, gamma, beta, stats, a, N, H, W, pool);
     return hipGetLastError();
 }
 
@@ -614,13 +655,20 @@ hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* st
     return hipGetLastError();
 }
 
+hipError_t launch_bn_bwd_final(const float* part, int G, int C, double nred, float* sums, float* dgamma, float* dbeta,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, s, part, G, C, nred, sums, dgamma, dbeta);
+    return hipGetLastError();
+}
+
 hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
-                            const float* part, int G, long N, int H, int W, int C, int pool, float* dz,
-                            float* dzsum_part, int* Gz, float* dgamma, float* dbeta, hipStream_t s)
+                            const float* sums, long N, int H, int W, int C, int pool, float* dz, float* dzsum_part,
+                            int* Gz, hipStream_t s)
 {
     *Gz = stat_grid(N * (pool ? H / 2 : H) * (pool ? W / 2 : W));
-    hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(*Gz), dim3(256), 0, s, da, r, stats, gamma, beta, part, G, N, H, W, C, pool, dz,
-                       dzsum_part, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(*Gz), dim3(256), 0, s, da, r, stats, gamma, beta, sums, N, H, W, C, pool, dz,
+                       dzsum_part);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ struct cs_trainer {
     DevBuf wf[6], wft[7], w7eff, ep_inf[6];
     // batch tensors
     DevBuf x, y, r[6], a[6], out, errpart, dz[7], da[6], stats[6];
-    DevBuf part_stats, part_bwd, dzsum_part[7], wpart[7], descs, scal;
+    DevBuf part_stats, part_bwd, bwd_sums, dzsum_part[7], wpart[7], descs, scal;
     int np_w[7], np_b[7];
     ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -141,6 +141,7 @@ int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int dev
     TFAIL(t->w7eff.ensure(16 * 32 * 4));
     TFAIL(t->part_stats.ensure((size_t)TRAIN_MAX_PARTS * 3 * 64 * 4));
     TFAIL(t->part_bwd.ensure((size_t)TRAIN_MAX_PARTS * 2 * 64 * 4));
+    TFAIL(t->bwd_sums.ensure(2 * 64 * 4));
     for (int l = 0; l < 7; ++l) {
         TFAIL(t->dzsum_part[l].ensure((size_t)TRAIN_MAX_PARTS * 64 * 4));
         TFAIL(t->wpart[l].ensure((size_t)TRAIN_MAX_PARTS * 9 * cin_of(l) * kRefChannels[l] * 4));
@@ -200,9 +201,10 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
         LCHK(launch_conv_train_fwd(l, in, t->wf[l].as<float>(), P + t->off_b[l], t->r[l].as<float>(), B, s));
         int G1 = 0;
         LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * Hc * Hc, C, t->part_stats.as<float>(), &G1, s));
-        LCHK(launch_bn_apply(t->r[l].as<float>(), t->part_stats.as<float>(), G1, C, P + t->off_g[l], P + t->off_be[l],
-                             t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l], MOV + t->off_mv[l],
-                             t->stats[l].as<float>(), t->a[l].as<float>(), B, Hc, Hc, pool, s));
+        LCHK(launch_bn_stats_final(t->part_stats.as<float>(), G1, C, t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l],
+                                   MOV + t->off_mv[l], t->stats[l].as<float>(), s));
+        LCHK(launch_bn_apply(t->r[l].as<float>(), C, P + t->off_g[l], P + t->off_be[l], t->stats[l].as<float>(),
+                             t->a[l].as<float>(), B, Hc, Hc, pool, s));
     }
     LCHK(launch_conv7_err(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6],
                           t->errpart.as<float>(), t->out.as<float>(), B, s));
@@ -218,9 +220,11 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
         int G2 = 0;
         LCHK(launch_bn_bwd_reduce(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
                                   P + t->off_be[l], B, Hc, Hc, C, pool, t->part_bwd.as<float>(), &G2, s));
+        LCHK(launch_bn_bwd_final(t->part_bwd.as<float>(), G2, C, (double)B * Hc * Hc, t->bwd_sums.as<float>(),
+                                 G + t->off_g[l], G + t->off_be[l], s));
         LCHK(launch_bn_bwd_dz(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
-                              P + t->off_be[l], t->part_bwd.as<float>(), G2, B, Hc, Hc, C, pool, t->dz[l].as<float>(),
-                              t->dzsum_part[l].as<float>(), &t->np_b[l], G + t->off_g[l], G + t->off_be[l], s));
+                              P + t->off_be[l], t->bwd_sums.as<float>(), B, Hc, Hc, C, pool, t->dz[l].as<float>(),
+                              t->dzsum_part[l].as<float>(), &t->np_b[l], s));
         const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
         LCHK(launch_wgrad(l, in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, &t->np_w[l], s));
         if (l > 0) LCHK(launch_conv_dgrad(l, t->dz[l].as<float>(), t->wft[l].as<float>(), t->da[l - 1].as<float>(), B, s));
