@@ -17,6 +17,8 @@
 // first half of the output transform, so neither transform needs cross-lane traffic.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace cs {
 
 namespace {
@@ -57,11 +59,23 @@ __device__ __forceinline__ void wn_store(float* strip, int idx, const f32x4& v)
 // MFMAs directly.  The four output-slice waves repeat the same transform (the VALU is otherwise
 // idle) but no transformed tensor goes through LDS and no barrier separates transform and product:
 // one barrier per item (strip double buffer) is all that is left.
+// DIAG: a diagnostic build that stamps s_memtime around the phases of every tile row and adds the
+// differences up per wave (never used for results or timing; `diag` = [blocks][4 waves][4] cycles:
+// prepare (LDS reads + input transform), MFMA issue, fold/epilogue/stores, barrier wait).
+__device__ __forceinline__ unsigned long long wn_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <bool DIAG>
 __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
     const float* __restrict__ in /* p1 [n][32][32][32] */, const float* __restrict__ ufrag,
     const float* __restrict__ ep /* [3][64] bias, bn scale, bn shift */, float* __restrict__ out /* p2 [n][16][16][64] */,
-    long n_cells)
+    long n_cells, unsigned long long* __restrict__ diag)
 {
+    unsigned long long d_prep = 0, d_mfma = 0, d_epi = 0, d_bar = 0, d_t = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int nsl = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output-channel slice
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
                 for (int q = 0; q < 2; ++q) {
                     // keep the scheduler from hoisting every step's patch loads to the top (register spills)
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (DIAG) { d_t = wn_stamp(); __builtin_amdgcn_sched_barrier(0); }
                     f32x4 w[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -121,11 +136,24 @@ __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
                         w[i] = da + SG[c] * db;
                     }
                     const f32x4 v[4] = {w[0] - w[2], w[1] + w[2], w[2] - w[1], w[1] - w[3]};   // xi = 4 r + c
+                    if constexpr (DIAG) {
+                        asm volatile("" ::"v"(v[0][0]), "v"(v[1][1]), "v"(v[2][2]), "v"(v[3][3]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned long long t = wn_stamp();
+                        d_prep += t - d_t; d_t = t;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[r][j], B[(4 * r + c) * 8 + 4 * q + j], acc[r], 0, 0, 0);
+                    if constexpr (DIAG) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned long long t = wn_stamp();
+                        d_mfma += t - d_t; d_t = t;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 // first half of the output transform: s = A^T M  (rows of M live in acc[0..3])
 #pragma unroll
@@ -151,9 +179,21 @@ __global__ __launch_bounds__(256, 2) void conv2_wino_kernel(
 #pragma unroll
                 for (int j = 0; j < WN_LPP; ++j) wn_store(nstrip, tid + 256 * (tr * WN_LPP + j), stg[j]);
             }
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = wn_stamp();
+                d_epi += t - d_t; d_t = t;
+            }
         }
         __syncthreads();   // this strip fully read; the next strip complete in the other buffer
+        if constexpr (DIAG) { const unsigned long long t = wn_stamp(); d_bar += t - d_t; d_t = t; }
         buf ^= 1;
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+            unsigned long long* o = diag + ((size_t)blockIdx.x * 4 + nsl) * 4;
+            o[0] = d_prep; o[1] = d_mfma; o[2] = d_epi; o[3] = d_bar;
+        }
     }
 }
 
@@ -182,26 +222,56 @@ size_t pack_wino_fragments(const float* hwio /* [3][3][32][64] */, float* dst)
     return total;
 }
 
+static unsigned long long* g_diag = nullptr;
+static int g_diag_blocks = 0;
+
 hipError_t launch_conv2_wino(const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                              hipStream_t stream)
 {
     static int resident = 0;
+    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
     if (!resident) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv2_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv2_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv2_wino_kernel, 256, WN_LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv2_wino_kernel<false>, 256, WN_LDS);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
+        if (diag) {
+            if ((e = hipMalloc(&g_diag, (size_t)resident * 16 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_diag_blocks = resident;
+        }
     }
     const long total = (long)n_cells * WN_NSTRIP;
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv2_wino_kernel, dim3(grid), dim3(256), WN_LDS, stream, in, ufrag, ep, out, (long)n_cells);
+    if (diag)
+        hipLaunchKernelGGL(conv2_wino_kernel<true>, dim3(grid), dim3(256), WN_LDS, stream, in, ufrag, ep, out, (long)n_cells, g_diag);
+    else
+        hipLaunchKernelGGL(conv2_wino_kernel<false>, dim3(grid), dim3(256), WN_LDS, stream, in, ufrag, ep, out, (long)n_cells,
+                           (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
 }  // namespace cs
+
+// Diagnostic only (CS_WINO_DIAG=1): per-wave phase cycles of the LAST conv2 launch, averaged over waves.
+extern "C" int cs_debug_wino_diag(double out4[4])
+{
+    using namespace cs;
+    if (!g_diag) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const size_t n = (size_t)g_diag_blocks * 16;
+    unsigned long long* h = new unsigned long long[n];
+    if (hipMemcpy(h, g_diag, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { delete[] h; return -3; }
+    for (int k = 0; k < 4; ++k) out4[k] = 0.0;
+    for (size_t i = 0; i < n; ++i) out4[i & 3] += (double)h[i];
+    for (int k = 0; k < 4; ++k) out4[k] /= (double)(n / 4);
+    delete[] h;
+    return 0;
+}
