@@ -1,3 +1,5 @@
+"""Runs the diagnostic build of the Winograd conv2 kernel (CS_WINO_DIAG=1: s_memtime stamps summed per wave)
+and prints the phase shares of the last launch.  Diagnostic only; run on an MI355X from the repo root."""
 import os, sys, ctypes as C
 os.environ["CS_WINO_DIAG"] = "1"
 sys.path.insert(0, "cell-image-analysis_amd")
