@@ -73,6 +73,10 @@ SIGNATURES = {
     "cs_layer_output": (_I, [_P, _P, _L, _I, _I, _P, _I]),
     "cs_scaler_pca": (_I, [_P, _P, _L, _I, _P, _I]),
     "cs_svm_decision": (_I, [_P, _P, _L, _I, _P, _P, _I]),
+    "cs_preproc_create": (_I, [_I, C.POINTER(_P)]),
+    "cs_preproc_free": (None, [_P]),
+    "cs_preprocess": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _L, C.c_double, _P, _P, _I]),
+    "cs_preproc_last_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "cs_synth_crops": (_I, [_P, C.c_uint64, _L, _L, C.c_int32, _P]),
     "cs_profile_enable": (_I, [_P, _I]),
     "cs_profile_reset": (_I, [_P]),

@@ -50,6 +50,29 @@ def blob_crops(seed: int, n: int, hw=spec.INPUT_HW) -> np.ndarray:
     return out
 
 
+def raw_crops(seed: int, n: int, dtype=np.uint8, min_side: int = 8, max_side: int = 120, flat_every: int = 0):
+    """n ragged bounding-box crops as a microscope channel delivers them (uint8 / uint16): a bright
+    cell-like blob with spots on a dim noisy background, sides uniform in [min_side, max_side].
+    With flat_every = k every k-th crop is low-contrast (CLAHE's clip/redistribute path works hard)."""
+    rng = np.random.default_rng(seed)
+    top = 255 if np.dtype(dtype) == np.uint8 else 65535
+    out = []
+    for i in range(n):
+        H, W = int(rng.integers(min_side, max_side + 1)), int(rng.integers(min_side, max_side + 1))
+        yy, xx = np.mgrid[0:H, 0:W]
+        cy, cx = rng.uniform(0.35 * H, 0.65 * H), rng.uniform(0.35 * W, 0.65 * W)
+        sy, sx = rng.uniform(0.15 * H, 0.3 * H), rng.uniform(0.15 * W, 0.3 * W)
+        img = 0.08 + 0.7 * np.exp(-(((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2))
+        for _ in range(3):
+            py, px = rng.integers(0, H), rng.integers(0, W)
+            img += 0.3 * np.exp(-((yy - py) ** 2 + (xx - px) ** 2) / rng.uniform(2.0, 6.0))
+        img += rng.normal(0.0, 0.04, size=(H, W))
+        if flat_every and i % flat_every == flat_every - 1:
+            img = 0.5 + 0.01 * img
+        out.append(np.round(np.clip(img, 0.0, 1.0) * top).astype(dtype))
+    return out
+
+
 def random_cae(seed: int = 42, hw=spec.INPUT_HW, channels=spec.CHANNELS, n_enc=spec.N_ENC,
                trivial_bn: bool = False) -> CAEWeights:
     """Glorot-uniform convs, zero biases (Keras defaults); BN gamma in [0.5,1.5], beta in

@@ -19,6 +19,8 @@
  *        encoder.predict + flatten      improved_detection.py:130-131, CAE...:401-402
  *   cs_layer_output, cs_scaler_pca, cs_svm_decision
  *        stage-level taps used by the parity tests (oracle inputs to each stage)
+ *   cs_preprocess
+ *        equalize_adapthist + resize of each crop   improved_detection.py:98-99, CAE...:92-93
  *   cs_synth_crops
  *        synthetic U[0,1) crops (no reference counterpart; benchmark/test input)
  *   cs_train_create / cs_train_step / cs_train_eval / cs_train_export
@@ -185,6 +187,33 @@ int cs_svm_decision(cs_model *m, const float *pca, int64_t n, int in_kind,
  * (seed, first_cell + i, pixel); bit-identical to oracle/cae_oracle.c:orc_synth_crops. */
 int cs_synth_crops(cs_model *m, uint64_t seed, int64_t first_cell, int64_t n, int32_t npix,
                    float *out_device);
+
+/* ---- crop preprocess (the caller side of the hot path) ----------------------------- */
+/* What the reference does to every bounding-box crop before compute_anomaly_scores sees it
+ * (improved_detection.py:98-99, CAE_improved_modeltrain.py:92-93):
+ *     exposure.equalize_adapthist(crop, clip_limit=0.02)  ->  resize(., (64, 64), anti_aliasing=True)
+ * and the float32 cast of improved_detection.py:122.  Arithmetic of scikit-image 0.18.3 /
+ * SciPy 1.7.1 (CLAHE bit-exact, resize in fp64).  Independent of cs_model: own handle, own stream. */
+typedef struct cs_preproc cs_preproc;
+typedef enum cs_pixel_type { CS_PIX_U8 = 0, CS_PIX_U16 = 1 } cs_pixel_type;   /* TIFF channel dtypes */
+
+int cs_preproc_create(int device_id, cs_preproc **out);
+void cs_preproc_free(cs_preproc *p);
+/* pixels:  ragged buffer of n_pixels elements (pixels_kind: host or device); crop i is the
+ *          row-major heights[i] x widths[i] block at element offsets[i].  offsets must ascend
+ *          and crops must not overlap.  offsets/heights/widths are host arrays of length n.
+ * Sides below 8 return CS_ERR_INVALID (kernel_size = shape // 8 would be 0: skimage raises),
+ * above 1024 CS_ERR_UNSUPPORTED.
+ * out:       [n][64][64] float32 (out_kind: host or device).
+ * clahe_out: optional stage tap, same layout/offsets as pixels (uint16, out_kind): the image
+ *            skimage's _clahe returns before the final rescale.  Elements between crops: 0 / untouched.
+ * n == 0 is valid and touches nothing. */
+int cs_preprocess(cs_preproc *p, const void *pixels, int pixel_type, int64_t n_pixels, int pixels_kind,
+                  const int64_t *offsets, const int32_t *heights, const int32_t *widths, int64_t n,
+                  double clip_limit, float *out, uint16_t *clahe_out, int out_kind);
+/* Device time (HIP events on the handle's stream around the kernel launches) and the pixel count
+ * of the last cs_preprocess call. */
+int cs_preproc_last_timing(const cs_preproc *p, double *kernel_ms, int64_t *pixels);
 
 /* ---- measurement ---------------------------------------------------------------- */
 /* When enabled, every kernel launch of this handle is bracketed by HIP events on the
