@@ -52,6 +52,15 @@ class ProductionMutantScreening:
             print(f"Error processing {image_path}: {e}")
             return [], []
 
+    def preprocess_crops(self, raw_crops) -> np.ndarray:
+        """:98-99 for a list of raw bounding-box crops (uint8 / uint16, ragged):
+        equalize_adapthist(clip_limit=0.02) + resize((64, 64), anti_aliasing=True) on the GPU.
+        A `cell_extractor` that segments images can call this instead of scikit-image."""
+        if getattr(self, "_preproc", None) is None:
+            from .preprocess import Preprocessor
+            self._preproc = Preprocessor(self.device_id)
+        return self._preproc(raw_crops)
+
     # ---- the hot path -------------------------------------------------------------------
     def compute_anomaly_scores(self, cell_images) -> Dict:
         """:117-153.  Same keys, dtypes and conventions as the reference's dict."""

@@ -30,7 +30,7 @@ struct CropDesc {
     int H, W;
 };
 
-static constexpr int PP_THREADS = 256;
+static constexpr int PP_THREADS = 512;
 static constexpr int PP_WAVES = PP_THREADS / 64;
 static constexpr int PP_NBINS = 256;
 static constexpr int PP_GRAY = 1 << 14;                 // NR_OF_GRAY, _adapthist.py:23
@@ -69,6 +69,15 @@ __device__ inline double wave_max(double v)
     return v;
 }
 
+// orders this wave's LDS traffic (a wave's ds operations execute in issue order; the fences keep the
+// compiler from moving them across)
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // workgroup min/max over per-thread values; every thread gets the result
 template <typename T>
 __device__ inline void block_minmax(T& lo, T& hi, T* red /* [2*PP_WAVES] */)
@@ -92,35 +101,52 @@ template <typename PIX> __device__ inline int to_u16(PIX v);
 template <> __device__ inline int to_u16<unsigned char>(unsigned char v) { return (int)v * 257; }   // img_as_uint 8 -> 16
 template <> __device__ inline int to_u16<unsigned short>(unsigned short v) { return (int)v; }
 
-// rescale_intensity(out_range=(0, 2^14-1)) + np.round + // bin_size  (_adapthist.py:78-81,139-143)
-__device__ inline int gray_bin(int v16, double imin, double range, bool flat)
+// rescale_intensity(out_range=(0, 2^14-1)) + np.round + // bin_size  (_adapthist.py:78-81,139-143).
+// skimage evaluates rint(fl(fl((v - imin) / range) * 16383)) in float64.  The exact rational
+// a*16383/range (a = v - imin < 2^16) is either a tie (2*rem == range) or at least 1/(2*range) >= 7.6e-6
+// away from one, while the two float64 roundings move it by < 4e-12: away from ties the integer
+// round-to-nearest below is the same number; exact ties take the float64 path itself.
+__device__ inline int gray_bin(int v16, int vlo, int irange, double rcp_range)
 {
-    double x;
-    if (!flat) {
-        x = __ddiv_rn(__dsub_rn((double)v16, imin), range);
-        x = __dmul_rn(x, (double)(PP_GRAY - 1));
+    int g;
+    if (irange != 0) {
+        const int a = v16 - vlo;
+        const unsigned num = (unsigned)a * (unsigned)(PP_GRAY - 1);                 // < 2^30
+        int q = (int)((double)num * rcp_range);
+        int rem = (int)num - q * irange;
+        if (rem < 0) { --q; rem += irange; } else if (rem >= irange) { ++q; rem -= irange; }
+        if (2 * rem > irange) {
+            g = q + 1;
+        } else if (2 * rem < irange) {
+            g = q;
+        } else {
+            const double x = __dmul_rn(__ddiv_rn((double)a, (double)irange), (double)(PP_GRAY - 1));
+            g = (int)rint(x);                           // rint: half-to-even, as np.round
+        }
     } else {
-        x = fmin(fmax((double)v16, 0.0), (double)(PP_GRAY - 1));
+        g = min(max(v16, 0), PP_GRAY - 1);              // constant crop: np.clip to the output range
     }
-    return (int)rint(x) / PP_BIN_SIZE;                  // rint: half-to-even, as np.round
+    return g / PP_BIN_SIZE;
+}
+
+// exact p / d for 0 <= p < 2^22, 1 <= d: float reciprocal estimate + one correction
+__device__ inline int fast_div(int p, int d, float rcp, int& rem)
+{
+    int q = (int)((float)p * rcp);
+    rem = p - q * d;
+    if (rem < 0) { --q; rem += d; } else if (rem >= d) { ++q; rem -= d; }
+    return q;
 }
 
 __device__ inline int reflect_once(int i, int n) { return i >= n ? 2 * (n - 1) - i : i; }   // np.pad 'reflect'
 
-__device__ inline int mirror_any(int i, int n)         // scipy.ndimage mode='mirror'
+// scipy.ndimage mode='mirror' and skimage's coord_map mode 'R' are the same map (reflect about the
+// centre of the edge pixel).  One reflection is enough here: the Gaussian radius int(4*sigma + 0.5)
+// with sigma = (n/64 - 1)/2 is below n/32, and the warp samples rows -1 .. n at most.
+__device__ inline int mirror_once(int i, int n)
 {
-    const int p = 2 * (n - 1);
-    i %= p;
-    if (i < 0) i += p;
-    return i >= n ? p - i : i;
-}
-
-__device__ inline int warp_reflect(int i, int n)       // skimage coord_map mode 'R'
-{
-    const int cmax = n - 1;
-    const int a = i < 0 ? -i : i;
-    const int q = a / cmax, r = a % cmax;
-    return (q & 1) ? cmax - r : r;
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
 }
 
 // clip_histogram (_adapthist.py:241-289) + map_histogram (:292-330) for one tile, one wave.
@@ -193,26 +219,27 @@ __device__ inline void clip_and_map(int h[4], int clim, double scale, int out[4]
 template <typename PIX>
 __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(const PIX* __restrict__ pix,
                                                                 const CropDesc* __restrict__ desc, double clip_limit,
-                                                                unsigned short* __restrict__ clahe,
-                                                                double* __restrict__ buf0, double* __restrict__ buf1,
-                                                                float* __restrict__ out)
+                                                                unsigned short* __restrict__ clahe, float* __restrict__ out)
 {
-    extern __shared__ unsigned short maps[];            // [tiles][256]
+    // [tiles][256] uint16 contrast maps during CLAHE; afterwards the same bytes hold one fp64 line of
+    // W values per wave for the resize
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    unsigned short* maps = (unsigned short*)dyn_lds;
     __shared__ unsigned int hist[PP_WAVES][PP_NBINS];
     __shared__ int red_i[2 * PP_WAVES];
-    __shared__ double red_d[2 * PP_WAVES];
-    __shared__ double wts[PP_MAX_TAPS + 1];
+    __shared__ double wts[2][PP_MAX_TAPS + 1];
+    __shared__ double crow[128], ccol[128];             // in-tile offset / tile size (tile side <= 1024/8)
+    __shared__ unsigned short rowtab[1024], coltab[1024];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const CropDesc d = desc[blockIdx.x];
     const int H = d.H, W = d.W, npx = H * W;
     const PIX* src = pix + d.off;
     unsigned short* cl = clahe + d.off;
-    double* b0 = buf0 + d.off;
-    double* b1 = buf1 + d.off;
     float* dst = out + (size_t)blockIdx.x * PP_OUT * PP_OUT;
 
-    // ---- A: intensity range of the crop --------------------------------------------------
+    // ---- A: intensity range of the crop, then the grey-level bin of every pixel (parked in cl[]) ----
+    const float rcpW = 1.0f / (float)W;
     int vlo = 0x7fffffff, vhi = -1;
     for (int p = tid; p < npx; p += PP_THREADS) {
         const int v = to_u16<PIX>(src[p]);
@@ -220,13 +247,42 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(const PIX* __res
         vhi = max(vhi, v);
     }
     block_minmax(vlo, vhi, red_i);
-    const double imin = (double)vlo, range = (double)(vhi - vlo);
-    const bool flat = vlo == vhi;
+    const int irange = vhi - vlo;
+    const double rcp_range = irange ? 1.0 / (double)irange : 0.0;
+    for (int p = tid; p < npx; p += PP_THREADS) cl[p] = (unsigned short)gray_bin(to_u16<PIX>(src[p]), vlo, irange, rcp_range);
 
-    // ---- B: per-tile histogram -> clip -> cumulative map ------------------------------------
+    // per-row / per-column block index and in-block offset of the padded image, the blend weights,
+    // and the two anti-aliasing kernels (scipy _gaussian_kernel1d: sigma = (n/64 - 1)/2, truncate 4)
     const int kh = H / 8, kw = W / 8;
+    const int ph0 = kh / 2, pw0 = kw / 2;
+    for (int r = tid; r < H; r += PP_THREADS) {
+        const int pr = r + ph0, br = pr / kh;
+        rowtab[r] = (unsigned short)((br << 8) | (pr - br * kh));
+    }
+    for (int c = tid; c < W; c += PP_THREADS) {
+        const int pc = c + pw0, bc = pc / kw;
+        coltab[c] = (unsigned short)((bc << 8) | (pc - bc * kw));
+    }
+    if (tid < kh) crow[tid] = __ddiv_rn((double)tid, (double)kh);
+    if (tid < kw) ccol[tid] = __ddiv_rn((double)tid, (double)kw);
+    const double sig_r = fmax(0.0, ((double)H / (double)PP_OUT - 1.0) / 2.0);
+    const double sig_c = fmax(0.0, ((double)W / (double)PP_OUT - 1.0) / 2.0);
+    const int lw_r = sig_r > 1e-15 ? (int)(4.0 * sig_r + 0.5) : -1;     // -1: no filter along this axis
+    const int lw_c = sig_c > 1e-15 ? (int)(4.0 * sig_c + 0.5) : -1;
+    if (tid >= PP_THREADS - 128 && (tid & 63) == 0) {                    // lane 0 of the last two waves
+        const int ax = (tid >> 6) & 1;
+        const double sg = ax ? sig_c : sig_r;
+        const int lw = ax ? lw_c : lw_r;
+        double sum = 0.0;
+        for (int j = -lw; j <= lw; ++j) sum += exp(-0.5 / (sg * sg) * (double)(j * j));
+        for (int j = 0; j <= lw; ++j) wts[ax][j] = exp(-0.5 / (sg * sg) * (double)(j * j)) / sum;
+    }
+    __syncthreads();                                     // publishes cl[] and the tables
+
+    // ---- B: per-tile histogram -> clip -> cumulative map; a wave owns a tile, no workgroup barrier ----
     const int nty = (H + kh - 1) / kh, ntx = (W + kw - 1) / kw;      // histogram tiles (= ns_hist)
     const int tiles = nty * ntx, tpx = kh * kw;
+    const float rcpkw = 1.0f / (float)kw;
     int clim;
     if (clip_limit > 0.0) {
         const double c = __dmul_rn(clip_limit, (double)tpx);
@@ -235,43 +291,37 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(const PIX* __res
         clim = tpx;
     }
     const double scale = __ddiv_rn((double)(PP_GRAY - 1), (double)tpx);
-    for (int t0 = 0; t0 < tiles; t0 += PP_WAVES) {
-        const int t = t0 + wave;
-        const bool live = t < tiles;
+    for (int t = wave; t < tiles; t += PP_WAVES) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) hist[wave][4 * lane + k] = 0;
-        __syncthreads();
-        if (live) {
-            const int ty = t / ntx, tx = t - ty * ntx;
-            for (int p = lane; p < tpx; p += 64) {
-                const int i = p / kw, j = p - i * kw;
-                const int r = reflect_once(ty * kh + i, H), c = reflect_once(tx * kw + j, W);
-                const int b = gray_bin(to_u16<PIX>(src[r * W + c]), imin, range, flat);
-                atomicAdd(&hist[wave][b], 1u);
-            }
+        wave_sync();
+        const int ty = t / ntx, tx = t - ty * ntx;
+        for (int p = lane; p < tpx; p += 64) {
+            int j;
+            const int i = fast_div(p, kw, rcpkw, j);
+            const int r = reflect_once(ty * kh + i, H), c = reflect_once(tx * kw + j, W);
+            atomicAdd(&hist[wave][cl[r * W + c]], 1u);
         }
-        __syncthreads();
-        if (live) {
-            int h[4], m[4];
+        wave_sync();
+        int h[4], m[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) h[k] = (int)hist[wave][4 * lane + k];
-            clip_and_map(h, clim, scale, m);
+        for (int k = 0; k < 4; ++k) h[k] = (int)hist[wave][4 * lane + k];
+        wave_sync();
+        clip_and_map(h, clim, scale, m);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) maps[(size_t)t * PP_NBINS + 4 * lane + k] = (unsigned short)m[k];
-        }
-        __syncthreads();
+        for (int k = 0; k < 4; ++k) maps[(size_t)t * PP_NBINS + 4 * lane + k] = (unsigned short)m[k];
     }
+    __syncthreads();
 
     // ---- C: blend the four neighbouring maps (float32 accumulation, skimage's edge order) --------
-    const int ph0 = kh / 2, pw0 = kw / 2;
     int ulo = 0x7fffffff, uhi = -1;
     for (int p = tid; p < npx; p += PP_THREADS) {
-        const int r = p / W, c = p - r * W;
-        const int b = gray_bin(to_u16<PIX>(src[p]), imin, range, flat);
-        const int pr = r + ph0, pc = c + pw0;
-        const int br = pr / kh, ir = pr - br * kh;
-        const int bc = pc / kw, ic = pc - bc * kw;
-        const double cr = __ddiv_rn((double)ir, (double)kh), cc = __ddiv_rn((double)ic, (double)kw);
+        int c;
+        const int r = fast_div(p, W, rcpW, c);
+        const int b = cl[p];
+        const int rt = rowtab[r], ct = coltab[c];
+        const int br = rt >> 8, bc = ct >> 8;
+        const double cr = crow[rt & 255], cc = ccol[ct & 255];
         const double wr[2] = {__dsub_rn(1.0, cr), cr}, wc[2] = {__dsub_rn(1.0, cc), cc};
         float acc = 0.0f;
 #pragma unroll
@@ -290,74 +340,67 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(const PIX* __res
         ulo = min(ulo, u);
         uhi = max(uhi, u);
     }
-    block_minmax(ulo, uhi, red_i);                       // also makes cl[] visible to the workgroup
+    block_minmax(ulo, uhi, red_i);                       // its barriers also retire the maps and publish cl[]
 
-    // ---- D: img_as_float + rescale_intensity (_adapthist.py:93-94) -> fp64 plane -------------------
-    const double rcp = 1.0 / 65535.0;
-    const double emin = __dmul_rn((double)ulo, rcp), erange = __dsub_rn(__dmul_rn((double)uhi, rcp), emin);
-    const bool eflat = ulo == uhi;
-    for (int p = tid; p < npx; p += PP_THREADS) {
-        const double x = __dmul_rn((double)cl[p], rcp);
-        b0[p] = eflat ? fmin(fmax(x, 0.0), 1.0) : __ddiv_rn(__dsub_rn(x, emin), erange);
-    }
-    __syncthreads();
-
-    // ---- E: anti-aliasing Gaussian, axis 0 then axis 1 (scipy gaussian_filter, mode='mirror') -----
-    double* cur = b0;
-    double* oth = b1;
-#pragma unroll 1
-    for (int axis = 0; axis < 2; ++axis) {
-        const int n_ax = axis == 0 ? H : W;
-        const double f = (double)n_ax / (double)PP_OUT;
-        const double sigma = fmax(0.0, (f - 1.0) / 2.0);
-        if (!(sigma > 1e-15)) continue;
-        const int lw = (int)(4.0 * sigma + 0.5);
-        if (tid == 0) {
-            double s = 0.0;
-            for (int j = -lw; j <= lw; ++j) s += exp(-0.5 / (sigma * sigma) * (double)(j * j));
-            for (int j = 0; j <= lw; ++j) wts[j] = exp(-0.5 / (sigma * sigma) * (double)(j * j)) / s;
-        }
-        __syncthreads();
-        for (int p = tid; p < npx; p += PP_THREADS) {
-            const int r = p / W, c = p - r * W;
-            double acc = cur[p] * wts[0];
-            if (axis == 0) {
-                for (int j = lw; j >= 1; --j)
-                    acc += (cur[mirror_any(r - j, H) * W + c] + cur[mirror_any(r + j, H) * W + c]) * wts[j];
-            } else {
-                for (int j = lw; j >= 1; --j)
-                    acc += (cur[r * W + mirror_any(c - j, W)] + cur[r * W + mirror_any(c + j, W)]) * wts[j];
-            }
-            oth[p] = acc;
-        }
-        __syncthreads();
-        double* t = cur; cur = oth; oth = t;
-    }
-
-    // ---- F: range of the filtered image (warp's clip=True) ----------------------------------------------
-    double lo = 1e300, hi = -1e300;
-    for (int p = tid; p < npx; p += PP_THREADS) {
-        const double v = cur[p];
-        lo = fmin(lo, v);
-        hi = fmax(hi, v);
-    }
-    block_minmax(lo, hi, red_d);
-
-    // ---- G: bilinear warp to 64x64, half-pixel centres, mode='reflect' (_warps.py:153-178) --------------
+    // ---- D: img_as_float + rescale_intensity + resize, fused -------------------------------------------
+    // skimage: eq = (u/65535 - min)/(max - min) (_adapthist.py:93-94), Gaussian along rows then columns,
+    // bilinear warp at r = H/64*(i+0.5)-0.5 (mode 'reflect'), clip to the filtered image's range.  Every
+    // step after the uint16 image is linear with weights that sum to 1, so the same numbers come from
+    // filtering + sampling (u - ulo) in fp64 and dividing by (uhi - ulo) at the end (differences ~1e-16
+    // relative; the result is rounded to float32 anyway), and the clip can only act on rounding noise:
+    // it becomes a clamp to [0,1].  A wave produces one output row: the vertically filtered and
+    // row-interpolated line Y[0..W) goes to LDS, then each lane filters + interpolates along it.
+    double* yline = (double*)dyn_lds + (size_t)wave * W;
     const double fr = (double)H / (double)PP_OUT, fc = (double)W / (double)PP_OUT;
     const double or_ = fr * 0.5 - 0.5, oc_ = fc * 0.5 - 0.5;
-    for (int p = tid; p < PP_OUT * PP_OUT; p += PP_THREADS) {
-        const int i = p >> 6, j = p & 63;
-        const double r = fr * (double)i + or_, c = fc * (double)j + oc_;
-        const double r0 = floor(r), c0 = floor(c);
-        const double dr = r - r0, dc = c - c0;
-        const int r0i = warp_reflect((int)r0, H), r1i = warp_reflect((int)ceil(r), H);
-        const int c0i = warp_reflect((int)c0, W), c1i = warp_reflect((int)ceil(c), W);
-        const double top = (1.0 - dc) * cur[r0i * W + c0i] + dc * cur[r0i * W + c1i];
-        const double bot = (1.0 - dc) * cur[r1i * W + c0i] + dc * cur[r1i * W + c1i];
-        double v = (1.0 - dr) * top + dr * bot;
-        v = fmin(fmax(v, lo), hi);
-        dst[p] = (float)v;                               // .astype('float32'), improved_detection.py:122
+    const bool eflat = ulo == uhi;
+    const double inv = eflat ? 0.0 : 1.0 / (double)(uhi - ulo);
+    const double cflat = fmin(fmax((double)ulo * (1.0 / 65535.0), 0.0), 1.0);
+    // column sample points of this lane
+    const double cpos = fc * (double)lane + oc_;
+    const double c0f = floor(cpos), dc = cpos - c0f;
+    const int c0 = (int)c0f, c1 = (int)ceil(cpos);
+    for (int i = wave; i < PP_OUT; i += PP_WAVES) {
+        const double rpos = fr * (double)i + or_;
+        const double r0f = floor(rpos), dr = rpos - r0f;
+        const int r0 = (int)r0f, r1 = (int)ceil(rpos);
+        for (int c = lane; c < W; c += 64) {
+            double y0, y1;
+            if (lw_r < 0) {
+                y0 = (double)((int)cl[mirror_once(r0, H) * W + c] - ulo);
+                y1 = (double)((int)cl[mirror_once(r1, H) * W + c] - ulo);
+            } else {
+                // the filtered image is sampled at mirror(r0), mirror(r1); taps mirror again around them
+                const int q0 = mirror_once(r0, H), q1 = mirror_once(r1, H);
+                y0 = (double)((int)cl[q0 * W + c] - ulo) * wts[0][0];
+                y1 = (double)((int)cl[q1 * W + c] - ulo) * wts[0][0];
+                for (int j = lw_r; j >= 1; --j) {
+                    const double w = wts[0][j];
+                    y0 += (double)((int)cl[mirror_once(q0 - j, H) * W + c] + (int)cl[mirror_once(q0 + j, H) * W + c] - 2 * ulo) * w;
+                    y1 += (double)((int)cl[mirror_once(q1 - j, H) * W + c] + (int)cl[mirror_once(q1 + j, H) * W + c] - 2 * ulo) * w;
+                }
+            }
+            yline[c] = (1.0 - dr) * y0 + dr * y1;
+        }
+        wave_sync();
+        double z0, z1;
+        const int q0 = mirror_once(c0, W), q1 = mirror_once(c1, W);
+        if (lw_c < 0) {
+            z0 = yline[q0];
+            z1 = yline[q1];
+        } else {
+            z0 = yline[q0] * wts[1][0];
+            z1 = yline[q1] * wts[1][0];
+            for (int j = lw_c; j >= 1; --j) {
+                const double w = wts[1][j];
+                z0 += (yline[mirror_once(q0 - j, W)] + yline[mirror_once(q0 + j, W)]) * w;
+                z1 += (yline[mirror_once(q1 - j, W)] + yline[mirror_once(q1 + j, W)]) * w;
+            }
+        }
+        const double z = (1.0 - dc) * z0 + dc * z1;
+        const double v = eflat ? cflat : fmin(fmax(z * inv, 0.0), 1.0);
+        dst[i * PP_OUT + lane] = (float)v;              // .astype('float32'), improved_detection.py:122
+        wave_sync();                                     // yline is rewritten in the next round
     }
 }
 
@@ -370,12 +413,12 @@ struct cs_preproc {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf pix, desc, clahe, buf0, buf1, out;
+    DevBuf pix, desc, clahe, out;
     double last_kernel_ms = 0.0;
     int64_t last_pixels = 0;
 };
 
-static const int64_t kChunkPixels = 32ll << 20;         // fp64 planes: 2 x 256 MB per chunk
+static const int64_t kChunkPixels = 256ll << 20;        // pixel span of one launch (staging + uint16 plane)
 static const int64_t kChunkCrops = 1 << 16;
 
 int cs_preproc_create(int device_id, cs_preproc** out)
@@ -449,14 +492,15 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
     while (i0 < n) {
         // a chunk: consecutive crops, bounded in count and in the pixel span the fp64 planes must cover
         int64_t i1 = i0, lo = offsets[i0], hi = offsets[i0];
-        int max_tiles = 0;
+        size_t lds = 0;
         while (i1 < n && i1 - i0 < kChunkCrops) {
             const int64_t H = heights[i1], W = widths[i1];
             const int64_t nlo = std::min(lo, offsets[i1]), nhi = std::max(hi, offsets[i1] + H * W);
             if (i1 > i0 && nhi - nlo > kChunkPixels) break;
             lo = nlo; hi = nhi;
             const int kh = (int)H / 8, kw = (int)W / 8;
-            max_tiles = std::max(max_tiles, (int)((H + kh - 1) / kh) * (int)((W + kw - 1) / kw));
+            const size_t tiles = (size_t)((H + kh - 1) / kh) * (size_t)((W + kw - 1) / kw);
+            lds = std::max(lds, std::max(tiles * PP_NBINS * sizeof(unsigned short), (size_t)PP_WAVES * (size_t)W * sizeof(double)));
             ++i1;
         }
         const int64_t nc = i1 - i0, span = hi - lo;
@@ -475,7 +519,6 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
         }
         if ((rc = p->desc.ensure((size_t)nc * sizeof(CropDesc)))) return rc;
         HIPCHK(hipMemcpyAsync(p->desc.p, hdesc.data(), (size_t)nc * sizeof(CropDesc), hipMemcpyHostToDevice, p->stream));
-        if ((rc = p->buf0.ensure((size_t)span * sizeof(double))) || (rc = p->buf1.ensure((size_t)span * sizeof(double)))) return rc;
         unsigned short* d_clahe;
         if (clahe_out && out_kind == CS_MEM_DEVICE) {
             d_clahe = clahe_out + lo;
@@ -492,18 +535,15 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
             d_out = p->out.as<float>();
         }
 
-        const size_t lds = (size_t)max_tiles * PP_NBINS * sizeof(unsigned short);
         HIPCHK(hipEventRecord(p->ev0, p->stream));
         if (pixel_type == CS_PIX_U8) {
             HIPCHK(hipFuncSetAttribute((const void*)preprocess_kernel<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3((unsigned)nc), dim3(PP_THREADS), lds, p->stream,
-                               (const unsigned char*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, p->buf0.as<double>(),
-                               p->buf1.as<double>(), d_out);
+                               (const unsigned char*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, d_out);
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)preprocess_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(preprocess_kernel<unsigned short>, dim3((unsigned)nc), dim3(PP_THREADS), lds, p->stream,
-                               (const unsigned short*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, p->buf0.as<double>(),
-                               p->buf1.as<double>(), d_out);
+                               (const unsigned short*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, d_out);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(p->ev1, p->stream));
