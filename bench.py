@@ -38,7 +38,8 @@ FLOP_PER_CELL = 100_270_080        # ALGORITHMIC: 2 x 50,135,040 conv MACs of th
 # the 16x16x4 MFMA.
 EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0, "conv5_up_relu_bn": 4.0 / 9.0, "conv6_up_relu_bn": 4.0 / 9.0,
                  "conv7_up_sigmoid_err": 4.0 / 9.0,
-                 "conv2_relu_bn_pool": 1.0 if os.environ.get("CS_NO_WINOGRAD") else 4.0 / 9.0}
+                 "conv2_relu_bn_pool": 1.0 if os.environ.get("CS_NO_WINOGRAD") else 4.0 / 9.0,
+                 "conv3_relu_bn_pool": 1.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO3")) else 4.0 / 9.0}
 BYTES_PER_CELL = 16_384 + 18       # algorithmic: read one crop, write 4 fp32/fp64-as-results + 2 int8
 
 

@@ -30,7 +30,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
                                             "finalize",           "synth_crops"};
 
 struct ConvSet {           // one weight set on device, packed for the kernels
-    DevBuf wino2;          // conv2 as Winograd F(2x2,3x3): transformed-kernel fragments
+    DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
     DevBuf ep[6];          // [3][cout] bias, bn_scale, bn_shift
     int n = 0;             // number of convs packed (6 for the autoencoder, 3 for encoder.keras)
@@ -43,6 +43,7 @@ struct cs_model {
     hipStream_t stream = nullptr;
     ConvSet ae, enc;
     bool shared_encoder = true;
+    bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
     DevBuf w7eff, b7;      // conv7: effective weights [16][32] and bias, on device
     // detector
@@ -133,10 +134,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
         }
         rc = upload(set.ep[l], ep.data(), ep.size() * sizeof(float));
         if (rc) return rc;
-        if (l == 1) {
-            tmp.resize(pack_wino_fragments(nullptr, nullptr));
-            pack_wino_fragments(w->kernel[l], tmp.data());
-            rc = upload(set.wino2, tmp.data(), tmp.size() * sizeof(float));
+        if (l == 1 || l == 2) {
+            tmp.resize(pack_wino_cs_fragments(l, nullptr, nullptr));
+            pack_wino_cs_fragments(l, w->kernel[l], tmp.data());
+            rc = upload(set.winocs[l], tmp.data(), tmp.size() * sizeof(float));
             if (rc) return rc;
         }
     }
@@ -257,9 +258,9 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
 {
     for (int l = first; l <= last && l < 6; ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
-        if (l == 1 && m->use_wino) {
+        if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
             LAUNCH(K_CONV1 + l, nc,
-                   launch_conv2_wino(in, set.wino2.as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+                   launch_conv_wino_cs(l, in, set.winocs[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
         LAUNCH(K_CONV1 + l, nc,

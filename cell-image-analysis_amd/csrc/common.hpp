@@ -31,10 +31,10 @@ enum KernelId {
 hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, const float* ep,
                             float* out, int64_t n_cells, hipStream_t stream, bool folded = false);
 size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* dst);
-// conv2 (32x32 grid, 32 -> 64 channels, relu + BN + 2x2 max-pool) as Winograd F(2x2,3x3): conv_wino.hip
-hipError_t launch_conv2_wino(const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
-                             hipStream_t stream);
-size_t pack_wino_fragments(const float* hwio, float* dst);
+// conv2 (layer 1) / conv3 (layer 2) as Winograd with the transform domain split by column over the waves: conv_wino_cs.hip
+hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
+                               hipStream_t stream);
+size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
 // Host-side packing of HWIO weights into the per-lane B fragments of launch_conv_mfma.
 // Returns the number of floats written (or required if dst == nullptr).
 size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);

@@ -190,6 +190,12 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     float bias = 0.0f, bns = 1.0f, bnt = 0.0f;
     if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) { bias = ep[co]; bns = ep[C::COUT + co]; bnt = ep[2 * C::COUT + co]; }
     if constexpr (C::EPI == EPI_RELU) bias = ep[co];
+    // Touch the loop-invariant registers here.  Their first use is inside the persistent loop, and the
+    // compiler's wait for these loads would sit there too -- a vmcnt(N) executed EVERY iteration that
+    // also waits for the strip prefetch issued just before it.
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
+    asm volatile("" : "+v"(bias), "+v"(bns), "+v"(bnt));
 
     // conv1: per-lane tap of each of the 3 K steps (k = 4 s + kq; k >= 9 is zero padding)
     int toff[3];

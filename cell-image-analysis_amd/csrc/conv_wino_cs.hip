@@ -1,0 +1,358 @@
+// conv_wino_cs.hip -- Winograd F(2x2, 3x3) for the two encoder convs that sit in front of a 2x2
+// max-pool, with the 4x4 transform domain split by COLUMN across the four waves of a workgroup:
+//   conv2: Conv2D 32->64 on the 32x32 grid  (CAE_improved_modeltrain.py:195-197)
+//   conv3: Conv2D 64->32 on the 16x16 grid  (:199-201)  -> the 8x8x32 `encoded` tensor
+//
+//   V = B^T d B       input transform of each 4x4 patch d (stride 2)
+//   M_xi = V_xi U_xi   16 products [16 tiles x cin] x [cin x cout], xi = 4 r + c          (fp32 MFMA)
+//   Y = A^T M A       2x2 outputs per tile = the max-pool window -> one value per tile and channel
+//
+// Wave c owns column c of the transform domain: it derives V[:, c] for ALL input channels (one
+// quarter of the transform, no redundancy between waves), keeps U[4r + c] for all output channels
+// in 128 VGPRs (4 r x cout/16 slices x cin/4 K steps), runs the 4 x (cout/16) x (cin/4) = 128 MFMAs
+// of a 16-tile group and folds rows (s = A^T M, in registers).  The column fold Y = s A crosses
+// waves: every wave leaves its s in LDS (32 / 16 KB), one barrier, then wave w finishes its share of
+// (slice, tile) pairs: bias -> relu -> BN -> 2x2 max -> store.  Compared with the previous kernel
+// (every wave transformed every column for its own output slice) the LDS patch reads and transform
+// VALU work drop 4x; the price is the exchange and a second barrier per group.
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace cs {
+
+namespace {
+
+template <int H_, int W_, int CIN_, int COUT_>
+struct WinoCfg {
+    static constexpr int H = H_, W = W_, CIN = CIN_, COUT = COUT_;
+    static constexpr int TW = W / 2;                     // tiles per tile row (16 | 8)
+    static constexpr int TR = 16 / TW;                   // tile rows per 16-tile group (1 | 2)
+    static constexpr int SR = 2 * TR;                    // conv rows per group
+    static constexpr int R = SR + 2, WP = W + 2;         // staged rows / cols incl. halo
+    // padded pixel stride: tiles step 2 pixels, so an ODD number of 16-B slots per pixel spreads the
+    // 16 tiles x 4 channel quads of a ds_read_b128 over distinct slots
+    static constexpr int PS = CIN + 4;
+    static constexpr int STRIP = R * WP * PS * 4;        // bytes, double buffered
+    static constexpr int NQ = CIN / 16, NS = COUT / 16, KS = CIN / 4;
+    static constexpr int NB = 4 * NS * KS;               // 128 for both layers
+    static constexpr int XCH = 4 * NS * 2 * 64 * 16;     // bytes: [wave c][slice][s0|s1][lane] f32x4
+    static constexpr int LDS = 2 * STRIP + XCH;
+    static constexpr int NGRP = H / SR;                  // groups per cell
+    static constexpr int C4 = CIN / 4, TOT = R * WP * C4;
+    static constexpr int NLD = (TOT + 255) / 256;        // per-thread 16-B loads per strip
+    static constexpr bool QOUTER = NQ > NS;              // which of V / accumulators is kept whole
+    static constexpr int FR = NS;                        // tile registers a wave finishes (4*NS units / 4 waves)
+    static_assert(NB == 128 && LDS <= 80 * 1024 && TW * TR == 16 && (NS == 2 || NS == 4), "layer does not fit this design");
+};
+using WinoL2 = WinoCfg<32, 32, 32, 64>;
+using WinoL3 = WinoCfg<16, 16, 64, 32>;
+
+// Strip staging.  The load is UNCONDITIONAL (halo / out-of-range lanes read a clamped in-range address)
+// and the zero padding is applied when the value is written to LDS: a load under a divergent branch
+// makes the compiler wait for it (vmcnt(0)) right where it is issued, which serialises the prefetch.
+template <class C>
+__device__ __forceinline__ bool wn_valid(int y0, int idx, int& sy, int& sx, int& c4)
+{
+    const int pix = idx / C::C4;
+    c4 = idx % C::C4;
+    const int r = pix / C::WP, c = pix % C::WP;
+    sy = y0 - 1 + r;
+    sx = c - 1;
+    return idx < C::TOT && sy >= 0 && sy < C::H && sx >= 0 && sx < C::W;
+}
+template <class C>
+__device__ __forceinline__ f32x4 wn_load(const float* __restrict__ in, long cell, int y0, int idx)
+{
+    const float* src = in + (size_t)cell * C::H * C::W * C::CIN;
+    int sy, sx, c4;
+    const bool ok = wn_valid<C>(y0, idx, sy, sx, c4);
+    const int off = ok ? (sy * C::W + sx) * C::CIN + c4 * 4 : 0;
+    return *(const f32x4*)(src + off);
+}
+template <class C>
+__device__ __forceinline__ void wn_store(float* strip, int y0, int idx, f32x4 v)
+{
+    int sy, sx, c4;
+    if (!wn_valid<C>(y0, idx, sy, sx, c4)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (idx < C::TOT) *(f32x4*)(strip + (idx / C::C4) * C::PS + c4 * 4) = v;
+}
+
+// DIAG: diagnostic build that stamps s_memtime at the phase boundaries of every group and sums the
+// differences per wave: [0] prefetch issue + transform + MFMA + row fold + exchange write, [1] next-strip
+// LDS writes, [2] wait at barrier A, [3] column fold + epilogue + stores, [4] wait at barrier B, [5] the
+// part of [0] spent issuing the next strip's global loads.  Never used for results or timing.
+__device__ __forceinline__ unsigned long long wcs_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <class C, bool DIAG>
+__global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __restrict__ in, const float* __restrict__ ufrag,
+                                                             const float* __restrict__ ep /* [3][cout] */,
+                                                             float* __restrict__ out, long n_cells,
+                                                             unsigned long long* __restrict__ diag)
+{
+    unsigned long long dg[6] = {0, 0, 0, 0, 0, 0}, dt = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const xch = (float*)(smem + 2 * C::STRIP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = transform-domain column
+    const int li = lane & 15, kq = lane >> 4;
+
+    float B[C::NB];
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) B[s] = ufrag[((size_t)wc * C::NB + s) * 64 + lane];
+
+    // V[:, c] = B^T (d B[:, c]);  d B[:, c] = d[:, ca] + sg * d[:, cb]
+    const int ca = wc == 0 ? 0 : (wc == 2 ? 2 : 1);
+    const int cb = wc == 2 ? 1 : (wc == 3 ? 3 : 2);
+    const float sg = wc == 1 ? 1.0f : -1.0f;
+    // patch of tile li inside the strip, this lane's channel quad
+    const int trow = li / C::TW, tcol = li % C::TW;
+    const int poff = ((2 * trow) * C::WP + 2 * tcol) * C::PS + 4 * kq;
+
+    // the (slice, tile register) share this wave finishes
+    const int fs = wc % C::NS, rbase = (wc / C::NS) * C::FR;
+    const int co = fs * 16 + li;
+    float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+    // Touch the epilogue constants here: their first use would otherwise be inside the loop, where the
+    // compiler's wait for them (vmcnt(0), every iteration) would also wait for the strip prefetch.
+    asm volatile("" : "+v"(bias), "+v"(bns), "+v"(bnt));
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
+
+    const long total = n_cells * C::NGRP;
+    const long first = blockIdx.x;
+    if (first >= total) return;
+#pragma unroll 4
+    for (int idx = tid; idx < C::TOT; idx += 256)
+        wn_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, idx, wn_load<C>(in, first / C::NGRP, (int)(first % C::NGRP) * C::SR, idx));
+    __syncthreads();
+
+    f32x4 stg[C::NLD];
+
+    int buf = 0;
+    for (long item = first; item < total; item += gridDim.x) {
+        const long cell = item / C::NGRP;
+        const int grp = (int)(item % C::NGRP);
+        const long nitem = item + gridDim.x;
+        const bool has_next = nitem < total;
+        const float* strip = (const float*)(smem + buf * C::STRIP);
+        float* nstrip = (float*)(smem + (buf ^ 1) * C::STRIP);
+
+        if constexpr (DIAG) dt = wcs_stamp();
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) stg[j] = wn_load<C>(in, nitem / C::NGRP, (int)(nitem % C::NGRP) * C::SR, tid + 256 * j);
+        }
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[5] += t - dt; }
+        const float* da_p = strip + poff + ca * C::PS;
+        const float* db_p = strip + poff + cb * C::PS;
+        auto transform = [&](int q, f32x4 v[4]) {
+            f32x4 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 da = *(const f32x4*)(da_p + i * C::WP * C::PS + 16 * q);
+                const f32x4 db = *(const f32x4*)(db_p + i * C::WP * C::PS + 16 * q);
+                w[i] = da + sg * db;
+            }
+            v[0] = w[0] - w[2]; v[1] = w[1] + w[2]; v[2] = w[2] - w[1]; v[3] = w[1] - w[3];
+        };
+        // row fold s = A^T M of one slice, left in LDS for the column fold
+        auto fold_store = [&](int s, const f32x4 acc[4]) {
+            f32x4 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+                s1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+            }
+            float* x = xch + ((size_t)((wc * C::NS + s) * 2) * 64 + lane) * 4;
+            *(f32x4*)x = s0;
+            *(f32x4*)(x + 64 * 4) = s1;
+        };
+
+        if constexpr (!C::QOUTER) {
+            // V for every channel group first (NQ x 16 VGPRs), then one output slice at a time
+            f32x4 V[C::NQ][4];
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) transform(q, V[q]);
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < C::NQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][r][j], B[(r * C::NS + s) * C::KS + 4 * q + j], acc[r], 0, 0, 0);
+                fold_store(s, acc);
+            }
+        } else {
+            // one channel group at a time (16 VGPRs of V), accumulators of every slice live
+            f32x4 acc[C::NS][4];
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s][r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) {
+                f32x4 v[4];
+                transform(q, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[r][j], B[(r * C::NS + s) * C::KS + 4 * q + j], acc[s][r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s) fold_store(s, acc[s]);
+        }
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[0] += t - dt; dt = t; }
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) wn_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, tid + 256 * j, stg[j]);
+        }
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[1] += t - dt; dt = t; }
+        __syncthreads();   // s of all four columns in LDS; this strip fully read; next strip complete
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[2] += t - dt; dt = t; }
+        // column fold Y = s A for this wave's (slice, tiles), then bias -> relu -> BN -> 2x2 max
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* x = xch + ((size_t)((c * C::NS + fs) * 2) * 64 + lane) * 4;
+            t0[c] = *(const f32x4*)x;
+            t1[c] = *(const f32x4*)(x + 64 * 4);
+        }
+        const f32x4 y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+        const f32x4 y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+        auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+#pragma unroll
+        for (int rr = 0; rr < C::FR; ++rr) {
+            float a, b, c2, d;
+            if constexpr (C::FR == 4) {
+                a = y00[rr]; b = y01[rr]; c2 = y10[rr]; d = y11[rr];
+            } else {   // FR == 2: registers rbase + rr with rbase in {0, 2} (wave-uniform)
+                a = rbase ? y00[2 + rr] : y00[rr]; b = rbase ? y01[2 + rr] : y01[rr];
+                c2 = rbase ? y10[2 + rr] : y10[rr]; d = rbase ? y11[2 + rr] : y11[rr];
+            }
+            const float res = fmaxf(fmaxf(post(a), post(b)), fmaxf(post(c2), post(d)));
+            const int t = 4 * kq + rbase + rr;                        // tile of the group (MFMA D row)
+            const int ty = grp * C::TR + t / C::TW, tx = t % C::TW;
+            out[(((size_t)cell * (C::H / 2) + ty) * (C::W / 2) + tx) * C::COUT + co] = res;
+        }
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[3] += t - dt; dt = t; }
+        __syncthreads();   // exchange area free again
+        if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[4] += t - dt; dt = t; }
+        buf ^= 1;
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) diag[((size_t)blockIdx.x * 4 + wc) * 6 + k] = dg[k];
+        }
+    }
+}
+
+template <class C>
+size_t pack_frags(const float* hwio, float* dst)
+{
+    // U = G g G^T per (cin, cout), evaluated in double and rounded once; B fragments
+    // [column c][(r * NS + s) * KS + 4 q + j][lane] = U[xi = 4 r + c][ci = 16 q + 4 kq + j][co = 16 s + li]
+    const size_t total = (size_t)4 * C::NB * 64;
+    if (!dst) return total;
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < C::NS; ++s)
+                for (int kk = 0; kk < C::KS; ++kk)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int li = lane & 15, kq = lane >> 4, q = kk >> 2, j = kk & 3;
+                        const int ci = 16 * q + 4 * kq + j, co = 16 * s + li;
+                        double u = 0.0;   // U[r][c] = sum_{a,b} G[r][a] g[a][b] G[c][b]
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b)
+                                u += G[r][a] * (double)hwio[((size_t)(a * 3 + b) * C::CIN + ci) * C::COUT + co] * G[c][b];
+                        dst[((size_t)c * C::NB + (r * C::NS + s) * C::KS + kk) * 64 + lane] = (float)u;
+                    }
+    return total;
+}
+
+unsigned long long* g_diag[3] = {nullptr, nullptr, nullptr};
+int g_diag_blocks[3] = {0, 0, 0};
+
+template <class C>
+hipError_t launch(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
+{
+    static int resident = 0;
+    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
+    if (!resident) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_cs_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_wino_cs_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_cs_kernel<C, false>, 256, C::LDS);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
+        if (diag) {
+            if ((e = hipMalloc(&g_diag[layer], (size_t)resident * 24 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_diag_blocks[layer] = resident;
+        }
+    }
+    const long total = (long)n_cells * C::NGRP;
+    if (total <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    if (diag)
+        hipLaunchKernelGGL((conv_wino_cs_kernel<C, true>), dim3(grid), dim3(256), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+                           g_diag[layer]);
+    else
+        hipLaunchKernelGGL((conv_wino_cs_kernel<C, false>), dim3(grid), dim3(256), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+                           (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst)
+{
+    return layer == 1 ? pack_frags<WinoL2>(hwio, dst) : pack_frags<WinoL3>(hwio, dst);
+}
+
+hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
+                               hipStream_t stream)
+{
+    if (layer == 1) return launch<WinoL2>(layer, in, ufrag, ep, out, n_cells, stream);
+    if (layer == 2) return launch<WinoL3>(layer, in, ufrag, ep, out, n_cells, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cs
+
+// Diagnostic only (CS_WINO_DIAG=1): per-wave phase cycles of the LAST launch of `layer`, averaged over waves.
+extern "C" int cs_debug_wino_cs_diag(int layer, double out6[6])
+{
+    using namespace cs;
+    if (layer < 1 || layer > 2 || !g_diag[layer]) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const size_t n = (size_t)g_diag_blocks[layer] * 24;
+    unsigned long long* h = new unsigned long long[n];
+    if (hipMemcpy(h, g_diag[layer], n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { delete[] h; return -3; }
+    for (int k = 0; k < 6; ++k) out6[k] = 0.0;
+    for (size_t i = 0; i < n; ++i) out6[i % 6] += (double)h[i];
+    for (int k = 0; k < 6; ++k) out6[k] /= (double)(n / 6);
+    delete[] h;
+    return 0;
+}

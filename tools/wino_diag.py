@@ -1,22 +1,34 @@
-"""Runs the diagnostic build of the Winograd conv2 kernel (CS_WINO_DIAG=1: s_memtime stamps summed per wave)
-and prints the phase shares of the last launch.  Diagnostic only; run on an MI355X from the repo root."""
+"""Runs the diagnostic build of the column-split Winograd kernels (CS_WINO_DIAG=1: s_memtime stamps summed
+per wave) and prints the phase shares of the last conv2 / conv3 launch.  Diagnostic only; run on an MI355X
+from the repo root."""
 import os, sys, ctypes as C
 os.environ["CS_WINO_DIAG"] = "1"
 sys.path.insert(0, "cell-image-analysis_amd")
 import numpy as np, torch
 from cellscreen import synth, _lib
 from cellscreen.engine import Engine
+N = 65536
 e = Engine.from_weights(synth.random_cae(42))
-x = torch.empty((32768, 64, 64), dtype=torch.float32, device="cuda")
+x = torch.empty((N, 64, 64), dtype=torch.float32, device="cuda")
 e.synth_crops(42, 0, x)
-e.set_chunk(32768)
-f = e.encode(x, which=0)
+e.set_chunk(N)
+f = e.encode(x, which=0)          # warm-up
+e.profile_enable(True)
+e.profile_reset()
+for _ in range(8):                # sustained load, so the clock is the one the bench sees
+    f = e.encode(x, which=0)
+prof = e.profile()
 lib = _lib.load_library()
-out = (C.c_double * 4)()
-rc = lib.cs_debug_wino_diag(out)
-v = list(out)
-tot = sum(v)
-print("rc", rc, "per-wave cycles (s_memtime ticks): prep %.0f  mfma %.0f  epilogue %.0f  barrier %.0f" % tuple(v))
-print("shares: prep %.1f%%  mfma %.1f%%  epi %.1f%%  barrier %.1f%%" % tuple(100 * a / tot for a in v))
-items = 32768 * 8 / 512
-print("items per WG %.1f; ticks per item %.0f; per tile-row %.0f (MFMA issue alone = 128 x 32 = 4096 cycles)" % (items, tot / items, tot / items / 2))
+names = ["loads+T+MFMA+fold", "strip writes", "barrier A", "finalize", "barrier B", "(load issue only)"]
+for layer, groups in ((1, 16), (2, 4)):
+    out = (C.c_double * 6)()
+    rc = lib.cs_debug_wino_cs_diag(layer, out)
+    v = list(out)
+    tot = sum(v[:5])
+    items = N * groups / 512
+    key = [k for k in prof if k.startswith(f"conv{layer + 1}_")][0]
+    ms = prof[key]["ms"] / prof[key]["launches"]
+    print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4096); "
+          f"launch {ms:.3f} ms -> s_memtime rate {tot / (ms * 1e-3) / 1e9:.3f} GHz")
+    for n_, a in zip(names, v):
+        print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
