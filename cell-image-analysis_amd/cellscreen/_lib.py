@@ -21,6 +21,11 @@ class CellScreenError(RuntimeError):
         self.status = status
 
 
+class CSAugAffine(C.Structure):
+    _fields_ = [("m", C.c_double * 4), ("off", C.c_double * 2), ("identity", C.c_int32), ("flip_h", C.c_int32),
+                ("flip_v", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CSCaeWeights(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
                 ("channels", C.c_int32 * CS_MAX_CONV),
@@ -91,6 +96,7 @@ SIGNATURES = {
     "cs_train_apply": (_I, [_P, C.c_float]),
     "cs_train_set_grad_buffer": (_I, [_P, _P]),
     "cs_train_eval": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cs_train_augment": (_I, [_P, _P, _L, _P, _P, _I]),
     "cs_train_export": (_I, [_P, _P, _P, _P]),
     "cs_train_tensor": (_I, [_P, _I, _I, _L, _P]),
     "cs_train_import": (_I, [_P, _P, _P]),

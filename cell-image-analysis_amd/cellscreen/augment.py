@@ -1,0 +1,137 @@
+"""Training augmentation on the GPU: the host-side half of the reference's
+
+    datagen = ImageDataGenerator(rotation_range=2, width_shift_range=0.02, height_shift_range=0.02,
+                                 zoom_range=0.02, horizontal_flip=True, vertical_flip=True, fill_mode='nearest')
+
+(CAE_improved_modeltrain.py:246-254), consumed as `datagen.flow(X_train, X_train, batch_size=32)` (:287):
+only the input batch is transformed, the target stays the original image.
+
+The class keeps Keras's names and draw order (`get_random_transform`: theta, tx (height), ty (width),
+zoom (zx, zy), flip_h, flip_v) and reduces each draw, in float64 and with Keras's matrix algebra
+(`apply_affine_transform` + `transform_matrix_offset_center`), to the 2x2 matrix + offset that
+scipy.ndimage.affine_transform takes.  The resampling itself (order=1, mode='nearest') and the flips
+run in libcellscreen (`cs_train_augment`, csrc/train.hip: augment_kernel); there is no CPU fallback.
+
+`center`: Keras 3 (the version that writes the reference's `.keras` files) centres the transform at
+size/2 - 0.5; keras-preprocessing <= 1.1.0 used size/2 + 0.5.  Neither is pinned by the reference."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+class ImageDataGenerator:
+    def __init__(self, rotation_range=0.0, width_shift_range=0.0, height_shift_range=0.0, zoom_range=0.0,
+                 horizontal_flip=False, vertical_flip=False, fill_mode="nearest", center: float = -0.5):
+        if fill_mode != "nearest":
+            raise NotImplementedError("the kernel implements fill_mode='nearest' (what the reference uses)")
+        if np.ndim(zoom_range) == 0:
+            zoom_range = (1.0 - zoom_range, 1.0 + zoom_range)
+        self.rotation_range = float(rotation_range)
+        self.width_shift_range = float(width_shift_range)
+        self.height_shift_range = float(height_shift_range)
+        self.zoom_range = (float(zoom_range[0]), float(zoom_range[1]))
+        self.horizontal_flip, self.vertical_flip = bool(horizontal_flip), bool(vertical_flip)
+        self.center = float(center)
+
+    @classmethod
+    def reference(cls) -> "ImageDataGenerator":
+        """The generator of CAE_improved_modeltrain.py:246-254."""
+        return cls(rotation_range=2, width_shift_range=0.02, height_shift_range=0.02, zoom_range=0.02,
+                   horizontal_flip=True, vertical_flip=True, fill_mode="nearest")
+
+    # ---- Keras's parameter draw -------------------------------------------------------------
+    def get_random_transform(self, img_shape, rng=np.random) -> dict:
+        h, w = img_shape[0], img_shape[1]
+        theta = rng.uniform(-self.rotation_range, self.rotation_range) if self.rotation_range else 0.0
+        if self.height_shift_range:
+            tx = rng.uniform(-self.height_shift_range, self.height_shift_range)
+            if self.height_shift_range < 1:
+                tx *= h
+        else:
+            tx = 0.0
+        if self.width_shift_range:
+            ty = rng.uniform(-self.width_shift_range, self.width_shift_range)
+            if self.width_shift_range < 1:
+                ty *= w
+        else:
+            ty = 0.0
+        if self.zoom_range[0] == 1 and self.zoom_range[1] == 1:
+            zx = zy = 1.0
+        else:
+            zx, zy = rng.uniform(self.zoom_range[0], self.zoom_range[1], 2)
+        flip_h = bool(rng.random() < 0.5) and self.horizontal_flip
+        flip_v = bool(rng.random() < 0.5) and self.vertical_flip
+        return dict(theta=float(theta), tx=float(tx), ty=float(ty), zx=float(zx), zy=float(zy),
+                    flip_h=bool(flip_h), flip_v=bool(flip_v))
+
+    # ---- Keras's matrix ---------------------------------------------------------------------------
+    def affine(self, p: dict, h: int, w: int):
+        """(2x2 matrix, offset) of apply_affine_transform, or None for the identity."""
+        m = None
+        if p["theta"] != 0:
+            t = np.deg2rad(p["theta"])
+            m = np.array([[np.cos(t), -np.sin(t), 0.0], [np.sin(t), np.cos(t), 0.0], [0.0, 0.0, 1.0]])
+        if p["tx"] != 0 or p["ty"] != 0:
+            s = np.array([[1.0, 0.0, p["tx"]], [0.0, 1.0, p["ty"]], [0.0, 0.0, 1.0]])
+            m = s if m is None else np.dot(m, s)
+        if p["zx"] != 1 or p["zy"] != 1:
+            z = np.array([[p["zx"], 0.0, 0.0], [0.0, p["zy"], 0.0], [0.0, 0.0, 1.0]])
+            m = z if m is None else np.dot(m, z)
+        if m is None:
+            return None
+        ox, oy = float(h) / 2 + self.center, float(w) / 2 + self.center
+        off = np.array([[1.0, 0.0, ox], [0.0, 1.0, oy], [0.0, 0.0, 1.0]])
+        rst = np.array([[1.0, 0.0, -ox], [0.0, 1.0, -oy], [0.0, 0.0, 1.0]])
+        m = np.dot(np.dot(off, m), rst)
+        return m[:2, :2], m[:2, 2]
+
+    def pack(self, params: Sequence[dict], h: int, w: int):
+        """The C ABI's array of cs_aug_affine for a batch of parameter dicts."""
+        arr = (L.CSAugAffine * len(params))()
+        for a, p in zip(arr, params):
+            am = self.affine(p, h, w)
+            if am is None:
+                a.identity = 1
+            else:
+                a.identity = 0
+                a.m[0], a.m[1], a.m[2], a.m[3] = am[0][0, 0], am[0][0, 1], am[0][1, 0], am[0][1, 1]
+                a.off[0], a.off[1] = am[1][0], am[1][1]
+            a.flip_h, a.flip_v = int(p["flip_h"]), int(p["flip_v"])
+        return arr
+
+    # ---- flow ---------------------------------------------------------------------------------
+    def random_batch(self, trainer, batch, rng=np.random):
+        """What one `next(datagen.flow(x, ...))` does to x: one independent draw per image.
+        Returns (augmented batch, list of the drawn parameter dicts)."""
+        n, h, w = batch.shape[0], batch.shape[1], batch.shape[2]
+        params: List[dict] = [self.get_random_transform((h, w), rng) for _ in range(n)]
+        return trainer.augment(batch, self.pack(params, h, w)), params
+
+
+class _GeneratorRng:
+    """Adapts numpy's Generator (used by cellscreen.training for shuffling) to the .uniform/.random
+    interface of the legacy np.random module that Keras draws from."""
+
+    def __init__(self, g):
+        self._g = g
+
+    def uniform(self, lo, hi, size=None):
+        return self._g.uniform(lo, hi, size)
+
+    def random(self):
+        return self._g.random()
+
+
+def reference_augment(trainer):
+    """augment(batch, rng) hook for ImprovedAnomalyDetectionTraining: the reference's generator."""
+    gen = ImageDataGenerator.reference()
+
+    def hook(batch, rng):
+        r = _GeneratorRng(rng) if isinstance(rng, np.random.Generator) else rng
+        return gen.random_batch(trainer, batch, r)[0]
+    return hook

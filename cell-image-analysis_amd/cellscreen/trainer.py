@@ -114,6 +114,21 @@ class Trainer:
         L.check(self._lib.cs_train_forward_backward(self._h, xp, yp, n, kind, C.byref(loss), C.byref(mae)))
         return loss.value, mae.value
 
+    def augment(self, x, transforms):
+        """cs_train_augment: x [n,64,64] (numpy or torch CUDA), transforms = (CSAugAffine * n) built by
+        cellscreen.augment.ImageDataGenerator.pack.  Returns a new array / tensor of the same kind."""
+        xb, xp, kind, n = self._buf(x)
+        assert len(transforms) == n
+        if kind == L.CS_MEM_HOST:
+            out = np.empty_like(xb)
+            op = out.ctypes.data
+        else:
+            import torch
+            out = torch.empty_like(xb)
+            op = out.data_ptr()
+        L.check(self._lib.cs_train_augment(self._h, xp, n, C.cast(transforms, C.c_void_p), op, kind))
+        return out
+
     def apply(self, lr: float = spec.ADAM_LR):
         L.check(self._lib.cs_train_apply(self._h, lr))
 

@@ -4,8 +4,9 @@ file roles, with the per-batch arithmetic (fit step, validation pass, reconstruc
 encoder features) executed by libcellscreen on the GPU.
 
 Out of scope: StarDist cell extraction / dataset assembly (:39-182), plots
-and text reports (:304-326, 345-392, 448-478).  Augmentation (:246-254) is a hook: pass
-`augment(batch, rng) -> batch`; the reference's quirk that only the INPUT is augmented while the
+and text reports (:304-326, 345-392, 448-478).  Augmentation (:246-254): `augment="reference"` runs the
+reference's ImageDataGenerator settings on the GPU (cellscreen/augment.py + cs_train_augment), or pass
+any `augment(batch, rng) -> batch`; the reference's quirk that only the INPUT is augmented while the
 target stays the original image (:287) is preserved.  Model files are written in the native
 format (model_io.save_model_dir) under the reference's roles: best (ModelCheckpoint, :270-275),
 final and encoder (:299-300), scaler/pca/detectors (:437-444, also as the reference's pickles)."""
@@ -65,6 +66,9 @@ class ImprovedAnomalyDetectionTraining:
         print(f"Training data: {X_train.shape + (1,)}")
         print(f"Validation data: {X_val.shape + (1,)}")
         tr = Trainer(self.create_improved_autoencoder(), device_id=self.device_id)
+        if self.augment == "reference":                                             # datagen of :246-254
+            from .augment import reference_augment
+            self.augment = reference_augment(tr)
         rng = np.random.default_rng(self.seed)
         steps = len(X_train) // self.batch_size                                     # steps_per_epoch (:288)
         hist = History()

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/cellscreen.h"
+
 namespace cs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -73,6 +75,8 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
                        hipStream_t s);
+// training augmentation: affine bilinear resample (nearest fill) + flips, one image per workgroup
+hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s);
 hipError_t launch_pack_frag(const float* hwio, int cin, int cout, int transposed, float* dst, hipStream_t s);
 hipError_t launch_pack_w7eff(const float* w7, float* weff, hipStream_t s);
 hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* beta, const float* mov_mean,

@@ -734,4 +734,43 @@ hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* be
     return hipGetLastError();
 }
 
+// ---- training augmentation ---------------------------------------------------------------
+// ImageDataGenerator.apply_transform for one 64x64 image (CAE_improved_modeltrain.py:246-254, :287):
+// scipy.ndimage.affine_transform(order=1, mode='nearest') at mat @ (r, c) + offset, then the flips.
+// Coordinates and interpolation in fp64 as SciPy does; the host builds mat/offset in double exactly as
+// Keras's apply_affine_transform would (cellscreen/augment.py), so the kernel only resamples.
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ in, const cs_aug_affine* __restrict__ tf,
+                                                      float* __restrict__ out, int H, int W)
+{
+    const cs_aug_affine a = tf[blockIdx.x];
+    const float* src = in + (size_t)blockIdx.x * H * W;
+    float* dst = out + (size_t)blockIdx.x * H * W;
+    for (int p = threadIdx.x; p < H * W; p += 256) {
+        const int r = p / W, c = p - r * W;
+        float v;
+        if (a.identity) {
+            v = src[p];
+        } else {
+            double rr = a.m[0] * (double)r + a.m[1] * (double)c + a.off[0];
+            double cc = a.m[2] * (double)r + a.m[3] * (double)c + a.off[1];
+            rr = fmin(fmax(rr, 0.0), (double)(H - 1));
+            cc = fmin(fmax(cc, 0.0), (double)(W - 1));
+            const int r0 = min((int)floor(rr), H - 2), c0 = min((int)floor(cc), W - 2);
+            const double fr = rr - (double)r0, fc = cc - (double)c0;
+            const double x00 = src[r0 * W + c0], x01 = src[r0 * W + c0 + 1];
+            const double x10 = src[(r0 + 1) * W + c0], x11 = src[(r0 + 1) * W + c0 + 1];
+            v = (float)((1.0 - fr) * ((1.0 - fc) * x00 + fc * x01) + fr * ((1.0 - fc) * x10 + fc * x11));
+        }
+        const int ro = a.flip_v ? H - 1 - r : r, co = a.flip_h ? W - 1 - c : c;
+        dst[ro * W + co] = v;
+    }
+}
+
+hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)n), dim3(256), 0, s, in, tf_dev, out, H, W);
+    return hipGetLastError();
+}
+
 }  // namespace cs

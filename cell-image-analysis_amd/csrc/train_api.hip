@@ -25,6 +25,7 @@ struct cs_trainer {
     DevBuf wf[6], wft[7], w7eff, ep_inf[6];
     // batch tensors
     DevBuf x, y, r[6], a[6], out, errpart, dz[7], da[6], stats[6];
+    DevBuf aug_tf, aug_in, aug_out;
     DevBuf part_stats, part_bwd, bwd_sums, dzsum_part[7], wpart[7], descs, scal;
     int np_w[7], np_b[7];
     ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
@@ -306,6 +307,33 @@ int cs_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int 
     }
     if (loss) *loss = (float)(s2 / ((double)n * kH * kW));
     if (mae) *mae = (float)(s1 / ((double)n * kH * kW));
+    return CS_OK;
+}
+
+int cs_train_augment(cs_trainer* t, const float* x, int64_t n, const cs_aug_affine* tf, float* out, int kind)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
+    if (n == 0) return CS_OK;
+    if (!x || !tf || !out) return fail(CS_ERR_INVALID, "NULL argument");
+    if (x == out) return fail(CS_ERR_INVALID, "out aliases x");
+    if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
+    HIPCHK(hipSetDevice(t->device));
+    const size_t bytes = (size_t)n * kH * kW * sizeof(float);
+    int rc;
+    if ((rc = t->aug_tf.ensure((size_t)n * sizeof(cs_aug_affine)))) return rc;
+    HIPCHK(hipMemcpyAsync(t->aug_tf.p, tf, (size_t)n * sizeof(cs_aug_affine), hipMemcpyHostToDevice, t->stream));
+    const float* d_in = x;
+    float* d_out = out;
+    if (kind == CS_MEM_HOST) {
+        if ((rc = t->aug_in.ensure(bytes)) || (rc = t->aug_out.ensure(bytes))) return rc;
+        HIPCHK(hipMemcpyAsync(t->aug_in.p, x, bytes, hipMemcpyHostToDevice, t->stream));
+        d_in = t->aug_in.as<float>();
+        d_out = t->aug_out.as<float>();
+    }
+    LCHK(launch_augment(d_in, t->aug_tf.as<cs_aug_affine>(), d_out, n, kH, kW, t->stream));
+    if (kind == CS_MEM_HOST) HIPCHK(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
     return CS_OK;
 }
 

@@ -259,6 +259,22 @@ int cs_train_apply(cs_trainer *t, float lr);
 int cs_train_set_grad_buffer(cs_trainer *t, float *device_buffer);
 /* Inference-mode loss / mae over n cells with the moving statistics (fit()'s validation pass). */
 int cs_train_eval(cs_trainer *t, const float *x, const float *y, int64_t n, int kind, float *loss, float *mae);
+/* Training augmentation: ImageDataGenerator(rotation_range=2, width/height_shift_range=0.02,
+ * zoom_range=0.02, horizontal/vertical_flip, fill_mode='nearest') applied to the INPUT batch only
+ * (CAE_improved_modeltrain.py:246-254, datagen.flow(X_train, X_train) at :287).
+ * One transform per image, already reduced on the host to what
+ * scipy.ndimage.affine_transform(order=1, mode='nearest') takes: input coordinate =
+ * m . (row, col) + off, built in double exactly as Keras's apply_affine_transform does
+ * (cellscreen/augment.py draws the parameters in Keras's order).  identity != 0 skips the
+ * resampling (Keras does when no rotation/shift/zoom was drawn); flips come last. */
+typedef struct cs_aug_affine {
+    double m[4];      /* row-major 2x2 */
+    double off[2];
+    int32_t identity, flip_h, flip_v, reserved;
+} cs_aug_affine;
+/* x, out: [n][64][64] fp32, both `kind`; tf: host array of n transforms.  out may not alias x. */
+int cs_train_augment(cs_trainer *t, const float *x, int64_t n, const cs_aug_affine *tf, float *out, int kind);
+
 /* Copies to host (each pointer may be NULL): trainable parameters, moving statistics, last gradients. */
 int cs_train_export(cs_trainer *t, float *params_host, float *moving_host, float *grads_host);
 /* Stage tap for parity tests: copies one tensor of the last forward_backward to host.
