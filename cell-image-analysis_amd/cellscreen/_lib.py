@@ -57,7 +57,7 @@ class CSModelInfo(C.Structure):
                 ("feature_dim", C.c_int32), ("n_components", C.c_int32),
                 ("n_sv_conservative", C.c_int32), ("n_sv_moderate", C.c_int32),
                 ("shared_encoder", C.c_int32), ("has_detector", C.c_int32), ("device_id", C.c_int32),
-                ("chunk_cells", C.c_int64)]
+                ("chunk_cells", C.c_int64), ("channels", C.c_int32 * CS_MAX_CONV), ("reference_arch", C.c_int32)]
 
 
 # every exported symbol of include/cellscreen.h: (restype, argtypes)

@@ -160,7 +160,7 @@ class Engine:
 
     def layer_output(self, crops, layer: int):
         buf, n, kind = self._crops(crops)
-        rows = spec.layer_table()
+        rows = spec.layer_table((self.info.height, self.info.width), tuple(self.info.channels[:self.info.n_conv]), self.info.n_enc)
         oh, ow = rows[layer]["out_hw"]
         o = self._alloc(kind, buf, (n, oh, ow, rows[layer]["cout"]), np.float32)
         L.check(self._lib.cs_layer_output(self._h, L._ptr(buf), n, kind, layer, L._ptr(o), kind))

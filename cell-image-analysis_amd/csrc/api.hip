@@ -36,12 +36,30 @@ struct ConvSet {           // one weight set on device, packed for the kernels
     int n = 0;             // number of convs packed (6 for the autoencoder, 3 for encoder.keras)
 };
 
+// weights of a non-reference architecture, as conv_generic.hip takes them (HWIO kernels + [3][cout] epilogue)
+struct GenSet { DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV]; };
+
+// The autoencoder's shape.  ref = the reference graph (64x64, 32-64-32 | 32-64-32-1): tuned kernels;
+// otherwise the same layer grammar with other sizes: conv_generic.hip.
+struct Arch {
+    bool ref = true;
+    int H = kH, W = kW, n_conv = kNConv, n_enc = kNEnc;
+    int ch[CS_MAX_CONV] = {0};
+    int gh[CS_MAX_CONV] = {0}, gw[CS_MAX_CONV] = {0};     // conv grid of layer l
+    size_t floats[CS_MAX_CONV] = {0};                     // stored output of layer l per cell (after pool)
+    size_t npix = (size_t)kH * kW;
+    size_t feat() const { return floats[n_enc - 1]; }
+    int cin(int l) const { return l == 0 ? 1 : ch[l - 1]; }
+};
+
 struct ProfEvent { int kid; hipEvent_t a, b; int64_t cells; };
 
 struct cs_model {
     int device = 0;
     hipStream_t stream = nullptr;
+    Arch arch;
     ConvSet ae, enc;
+    GenSet gae, genc;
     bool shared_encoder = true;
     bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
@@ -54,7 +72,7 @@ struct cs_model {
     // workspace (per chunk)
     int64_t chunk = 16384;
     int64_t ws_cells = 0;
-    DevBuf xin, act[6], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
+    DevBuf xin, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
     // profiling
     bool prof = false;
     std::vector<ProfEvent> pending;
@@ -92,6 +110,60 @@ int check_arch(const cs_cae_weights* w, int expect_convs, const char* what)
         const bool has_bn = l < kNConv - 1;
         if (has_bn && (!w->bn_gamma[l] || !w->bn_beta[l] || !w->bn_mean[l] || !w->bn_var[l]))
             return fail(CS_ERR_INVALID, "%s: conv %d BatchNormalization arrays are NULL", what, l);
+    }
+    return CS_OK;
+}
+
+// Fills `a` from a weight set and decides which kernels serve it.  Generic architectures must follow the
+// reference's grammar: n_enc x (conv, BN, pool), conv + BN, (n_enc - 1) x (upsample-fed conv + BN), upsample-fed
+// conv with 1 filter + sigmoid -- i.e. n_conv = 2 n_enc + 1 (CAE_improved_modeltrain.py:188-216).
+int describe_arch(const cs_cae_weights* w, Arch& a)
+{
+    if (!w) return fail(CS_ERR_INVALID, "autoencoder weights are NULL");
+    a.H = w->height; a.W = w->width; a.n_conv = w->n_conv; a.n_enc = w->n_enc;
+    if (a.n_conv < 3 || a.n_conv > CS_MAX_CONV || a.n_enc < 1 || a.n_conv != 2 * a.n_enc + 1)
+        return fail(CS_ERR_UNSUPPORTED, "autoencoder: n_conv=%d n_enc=%d is not the reference grammar (n_conv = 2 n_enc + 1)", a.n_conv, a.n_enc);
+    if (a.H <= 0 || a.W <= 0 || a.H % (1 << a.n_enc) || a.W % (1 << a.n_enc))
+        return fail(CS_ERR_UNSUPPORTED, "autoencoder: input %dx%d is not divisible by 2^n_enc", a.H, a.W);
+    a.ref = a.H == kH && a.W == kW && a.n_conv == kNConv && a.n_enc == kNEnc;
+    for (int l = 0; l < a.n_conv; ++l) {
+        a.ch[l] = w->channels[l];
+        if (a.ch[l] <= 0) return fail(CS_ERR_INVALID, "autoencoder: conv %d has %d filters", l, a.ch[l]);
+        if (a.ref && a.ch[l] != kRefChannels[l]) a.ref = false;
+    }
+    if (a.ch[a.n_conv - 1] != 1) return fail(CS_ERR_UNSUPPORTED, "autoencoder: the last conv must have 1 filter (has %d)", a.ch[a.n_conv - 1]);
+    int h = a.H, wd = a.W;                                 // stored size of the tensor the next conv reads
+    for (int l = 0; l < a.n_conv; ++l) {
+        if (l > a.n_enc) { h *= 2; wd *= 2; }             // behind an UpSampling2D
+        a.gh[l] = h; a.gw[l] = wd;
+        if (l < a.n_enc) { h /= 2; wd /= 2; }             // MaxPooling2D
+        a.floats[l] = (size_t)h * wd * a.ch[l];
+    }
+    a.npix = (size_t)a.H * a.W;
+    if (!a.ref) {
+        char why[160];
+        for (int l = 0; l < a.n_conv; ++l)
+            if (!conv_generic_supported(a.gh[l], a.gw[l], a.cin(l), a.ch[l], why, sizeof why))
+                return fail(CS_ERR_UNSUPPORTED, "autoencoder conv %d: %s", l, why);
+    }
+    for (int l = 0; l < a.n_conv; ++l) {
+        if (!w->kernel[l] || !w->bias[l]) return fail(CS_ERR_INVALID, "autoencoder: conv %d kernel/bias is NULL", l);
+        if (l < a.n_conv - 1 && (!w->bn_gamma[l] || !w->bn_beta[l] || !w->bn_mean[l] || !w->bn_var[l]))
+            return fail(CS_ERR_INVALID, "autoencoder: conv %d BatchNormalization arrays are NULL", l);
+    }
+    return CS_OK;
+}
+
+// encoder.keras weight set: must be the autoencoder's encoder half in shape
+int check_encoder(const cs_cae_weights* e, const Arch& a)
+{
+    if (e->height != a.H || e->width != a.W || e->n_conv != a.n_enc)
+        return fail(CS_ERR_UNSUPPORTED, "encoder: %dx%d with %d convs does not match the autoencoder's encoder half (%dx%d, %d)",
+                    e->height, e->width, e->n_conv, a.H, a.W, a.n_enc);
+    for (int l = 0; l < a.n_enc; ++l) {
+        if (e->channels[l] != a.ch[l]) return fail(CS_ERR_UNSUPPORTED, "encoder: conv %d has %d filters, the autoencoder %d", l, e->channels[l], a.ch[l]);
+        if (!e->kernel[l] || !e->bias[l] || !e->bn_gamma[l] || !e->bn_beta[l] || !e->bn_mean[l] || !e->bn_var[l])
+            return fail(CS_ERR_INVALID, "encoder: conv %d arrays are NULL", l);
     }
     return CS_OK;
 }
@@ -145,11 +217,33 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
     return CS_OK;
 }
 
-static bool same_encoder(const cs_cae_weights* a, const cs_cae_weights* e)
+// Generic architectures: HWIO kernels as they are + the [3][cout] epilogue (bias only for the sigmoid conv).
+static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int count)
+{
+    for (int l = 0; l < count; ++l) {
+        const int cin = a.cin(l), cout = a.ch[l];
+        int rc = upload(set.w[l], w->kernel[l], sizeof(float) * 9 * cin * cout);
+        if (rc) return rc;
+        std::vector<float> ep(3 * cout, 0.0f);
+        const bool has_bn = w->bn_gamma[l] != nullptr;
+        for (int c = 0; c < cout; ++c) {
+            ep[c] = w->bias[l][c];
+            if (has_bn) {
+                const float s_ = w->bn_gamma[l][c] / sqrtf(w->bn_var[l][c] + w->bn_eps);
+                ep[cout + c] = s_;
+                ep[2 * cout + c] = w->bn_beta[l][c] - w->bn_mean[l][c] * s_;
+            }
+        }
+        if ((rc = upload(set.ep[l], ep.data(), ep.size() * sizeof(float)))) return rc;
+    }
+    return CS_OK;
+}
+
+static bool same_encoder(const cs_cae_weights* a, const cs_cae_weights* e, const Arch& ar)
 {
     if (a->bn_eps != e->bn_eps) return false;
-    for (int l = 0; l < kNEnc; ++l) {
-        const int cin = l == 0 ? 1 : kRefChannels[l - 1], cout = kRefChannels[l];
+    for (int l = 0; l < ar.n_enc; ++l) {
+        const int cin = ar.cin(l), cout = ar.ch[l];
         if (memcmp(a->kernel[l], e->kernel[l], sizeof(float) * 9 * cin * cout)) return false;
         if (memcmp(a->bias[l], e->bias[l], sizeof(float) * cout)) return false;
         if (memcmp(a->bn_gamma[l], e->bn_gamma[l], sizeof(float) * cout)) return false;
@@ -187,10 +281,10 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
 {
     if (cells > m->ws_cells) {
         int rc;
-        if ((rc = m->xin.ensure((size_t)cells * kH * kW * sizeof(float)))) return rc;
-        for (int l = 0; l < 6; ++l)
-            if ((rc = m->act[l].ensure((size_t)cells * kLayerFloats[l] * sizeof(float)))) return rc;
-        if ((rc = m->featE.ensure((size_t)cells * kLayerFloats[2] * sizeof(float)))) return rc;
+        if ((rc = m->xin.ensure((size_t)cells * m->arch.npix * sizeof(float)))) return rc;
+        for (int l = 0; l < m->arch.n_conv - 1; ++l)
+            if ((rc = m->act[l].ensure((size_t)cells * m->arch.floats[l] * sizeof(float)))) return rc;
+        if ((rc = m->featE.ensure((size_t)cells * m->arch.feat() * sizeof(float)))) return rc;
         if ((rc = m->pca.ensure((size_t)cells * 256 * sizeof(float)))) return rc;
         if ((rc = m->errpart.ensure((size_t)cells * 8 * sizeof(float)))) return rc;
         for (int d = 0; d < 2; ++d) {
@@ -202,8 +296,8 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
         if ((rc = m->o_mae.ensure((size_t)cells * sizeof(float)))) return rc;
         m->ws_cells = cells;
     }
-    if (need_recon) {
-        int rc = m->recon.ensure((size_t)m->ws_cells * kH * kW * sizeof(float));
+    if (need_recon || !m->arch.ref) {   // the generic path always materialises the reconstruction
+        int rc = m->recon.ensure((size_t)m->ws_cells * m->arch.npix * sizeof(float));
         if (rc) return rc;
     }
     return CS_OK;
@@ -253,9 +347,28 @@ static int drain_profile(cs_model* m)
 // Runs convs [first, last] (0-based, inclusive) of weight set `set` on `nc` cells.
 // Layer l reads act[l-1] (or x for l == 0) and writes act[l]; conv 7 (index 6) writes
 // errpart (and recon when asked).
+static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int64_t nc, int first, int last, float* recon)
+{
+    const Arch& a = m->arch;
+    for (int l = first; l <= last; ++l) {
+        const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        const bool is_last = l == a.n_conv - 1;
+        float* out = is_last ? (recon ? recon : m->recon.as<float>()) : m->act[l].as<float>();
+        const int epi = is_last ? GEN_EPI_SIGMOID : (l < a.n_enc ? GEN_EPI_BN_POOL : GEN_EPI_BN);
+        const int kid = l < 6 ? K_CONV1 + l : K_CONV7_ERR;       // profile bucket: by position
+        LAUNCH(kid, nc,
+               launch_conv_generic(in, set.w[l].as<float>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],
+                                   l > a.n_enc, epi, m->stream));
+        if (is_last)
+            LAUNCH(K_CONV7_ERR, nc, launch_recon_err(out, x, nc, (int)a.npix, m->errpart.as<float>(), m->stream));
+    }
+    return CS_OK;
+}
+
 static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc, int first, int last,
                      float* recon)
 {
+    if (!m->arch.ref) return run_convs_generic(m, &set == &m->enc ? m->genc : m->gae, x, nc, first, last, recon);
     for (int l = first; l <= last && l < 6; ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
@@ -354,33 +467,41 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
 {
     if (!out) return fail(CS_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    int rc = check_arch(autoencoder, kNConv, "autoencoder");
+    Arch arch;
+    int rc = describe_arch(autoencoder, arch);
     if (rc) return rc;
-    if (encoder && (rc = check_arch(encoder, kNEnc, "encoder"))) return rc;
+    if (arch.ref && (rc = check_arch(autoencoder, kNConv, "autoencoder"))) return rc;
+    if (encoder && (rc = check_encoder(encoder, arch))) return rc;
     if ((rc = require_gfx950(device_id))) return rc;
 
     cs_model* m = new (std::nothrow) cs_model();
     if (!m) return fail(CS_ERR_NOMEM, "host allocation failed");
     m->device = device_id;
+    m->arch = arch;
 #define FAIL_IF(x) do { int r__ = (x); if (r__) { delete m; return r__; } } while (0)
     {
         hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete m; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     }
-    FAIL_IF(pack_set(m->ae, autoencoder, 6));
-    {
+    if (arch.ref) {
+        FAIL_IF(pack_set(m->ae, autoencoder, 6));
         float weff[16 * 32];
         conv7_effective_weights(autoencoder->kernel[6], weff);
         FAIL_IF(upload(m->w7eff, weff, sizeof weff));
         FAIL_IF(upload(m->b7, autoencoder->bias[6], sizeof(float)));
+    } else {
+        FAIL_IF(pack_generic(m->gae, autoencoder, arch, arch.n_conv));
     }
-    m->shared_encoder = !encoder || same_encoder(autoencoder, encoder);
-    if (!m->shared_encoder) FAIL_IF(pack_set(m->enc, encoder, kNEnc));
+    m->shared_encoder = !encoder || same_encoder(autoencoder, encoder, arch);
+    if (!m->shared_encoder) {
+        if (arch.ref) FAIL_IF(pack_set(m->enc, encoder, kNEnc));
+        else FAIL_IF(pack_generic(m->genc, encoder, arch, arch.n_enc));
+    }
 
     if (det) {
-        if (det->n_features != (int)kLayerFloats[2]) {
+        if (det->n_features != (int)arch.feat()) {
             delete m;
-            return fail(CS_ERR_INVALID, "detector n_features=%d but the encoder emits %zu", det->n_features, kLayerFloats[2]);
+            return fail(CS_ERR_INVALID, "detector n_features=%d but the encoder emits %zu", det->n_features, arch.feat());
         }
         if (det->n_components <= 0 || det->n_components > 128 || !det->scaler_center || !det->scaler_scale ||
             !det->pca_components || !det->pca_mean_proj) {
@@ -519,8 +640,10 @@ int cs_model_get_info(const cs_model* m, cs_model_info* info)
 {
     if (!m || !info) return fail(CS_ERR_INVALID, "NULL argument");
     memset(info, 0, sizeof *info);
-    info->height = kH; info->width = kW; info->n_conv = kNConv; info->n_enc = kNEnc;
-    info->feature_dim = (int32_t)kLayerFloats[2];
+    info->height = m->arch.H; info->width = m->arch.W; info->n_conv = m->arch.n_conv; info->n_enc = m->arch.n_enc;
+    info->feature_dim = (int32_t)m->arch.feat();
+    for (int l = 0; l < m->arch.n_conv; ++l) info->channels[l] = m->arch.ch[l];
+    info->reference_arch = m->arch.ref ? 1 : 0;
     info->n_components = m->C;
     info->n_sv_conservative = m->svm[0].nsv;
     info->n_sv_moderate = m->svm[1].nsv;
@@ -551,7 +674,7 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
                             m->svm[d].nsv, m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho,
                             m->dec[d].as<double>(), nc, m->stream));
     LAUNCH(K_FINALIZE, nc,
-           launch_finalize(with_err ? m->errpart.as<float>() : nullptr, 4, kH * kW, m->dec[0].as<double>(),
+           launch_finalize(with_err ? m->errpart.as<float>() : nullptr, 4, (int)m->arch.npix, m->dec[0].as<double>(),
                            m->dec[1].as<double>(), mse, mae, sc, sm, pc, pm, nc, m->stream));
     return CS_OK;
 }
@@ -571,14 +694,14 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* x;
-        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
-        if ((rc = run_convs(m, m->ae, x, nc, 0, 6, nullptr))) return rc;
-        const float* feat = m->act[2].as<float>();
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, m->arch.npix, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, nullptr))) return rc;
+        const float* feat = m->act[m->arch.n_enc - 1].as<float>();
         if (!m->shared_encoder) {
             // encoder.keras differs from the autoencoder's encoder half: second encoder pass
             // (improved_detection.py:130), after the decoder has consumed act[2].
-            if ((rc = run_convs(m, m->enc, x, nc, 0, 2, nullptr))) return rc;
-            feat = m->act[2].as<float>();
+            if ((rc = run_convs(m, m->enc, x, nc, 0, m->arch.n_enc - 1, nullptr))) return rc;
+            feat = m->act[m->arch.n_enc - 1].as<float>();
         }
         float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
         float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
@@ -613,18 +736,18 @@ int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, f
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* x;
-        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
-        float* d_rec = !recon ? nullptr : (out_kind == CS_MEM_DEVICE ? recon + (size_t)off * kH * kW : m->recon.as<float>());
-        if ((rc = run_convs(m, m->ae, x, nc, 0, 6, d_rec))) return rc;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, m->arch.npix, m->xin, &x))) return rc;
+        float* d_rec = !recon ? nullptr : (out_kind == CS_MEM_DEVICE ? recon + (size_t)off * m->arch.npix : m->recon.as<float>());
+        if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, d_rec))) return rc;
         float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
         float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
         LAUNCH(K_FINALIZE, nc,
-               launch_finalize(m->errpart.as<float>(), 4, kH * kW, nullptr, nullptr, d_mse, d_mae, nullptr, nullptr,
+               launch_finalize(m->errpart.as<float>(), 4, (int)m->arch.npix, nullptr, nullptr, d_mse, d_mae, nullptr, nullptr,
                                nullptr, nullptr, nc, m->stream));
         if ((rc = stage_out(m, mse, out_kind, off, nc, d_mse))) return rc;
         if ((rc = stage_out(m, mae, out_kind, off, nc, d_mae))) return rc;
         if (host_recon)
-            HIPCHK(hipMemcpyAsync(recon + (size_t)off * kH * kW, d_rec, (size_t)nc * kH * kW * sizeof(float),
+            HIPCHK(hipMemcpyAsync(recon + (size_t)off * m->arch.npix, d_rec, (size_t)nc * m->arch.npix * sizeof(float),
                                   hipMemcpyDeviceToHost, m->stream));
         if (crops_kind == CS_MEM_HOST || out_kind == CS_MEM_HOST) HIPCHK(hipStreamSynchronize(m->stream));
     }
@@ -643,13 +766,13 @@ int cs_encode(cs_model* m, const float* crops, int64_t n, int crops_kind, int wh
     const int64_t ch = n < m->chunk ? n : m->chunk;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
     const ConvSet& set = (which == 1 && !m->shared_encoder) ? m->enc : m->ae;
-    const size_t fl = kLayerFloats[2];
+    const size_t fl = m->arch.feat();
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* x;
-        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
-        if ((rc = run_convs(m, set, x, nc, 0, 2, nullptr))) return rc;
-        HIPCHK(hipMemcpyAsync(features + (size_t)off * fl, m->act[2].p, (size_t)nc * fl * sizeof(float),
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, m->arch.npix, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, set, x, nc, 0, m->arch.n_enc - 1, nullptr))) return rc;
+        HIPCHK(hipMemcpyAsync(features + (size_t)off * fl, m->act[m->arch.n_enc - 1].p, (size_t)nc * fl * sizeof(float),
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
@@ -663,17 +786,18 @@ int cs_layer_output(cs_model* m, const float* crops, int64_t n, int crops_kind, 
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
     if (n == 0) return CS_OK;
     if (!crops || !out) return fail(CS_ERR_INVALID, "crops/out is NULL");
-    if (layer < 0 || layer >= kNConv) return fail(CS_ERR_INVALID, "layer must be in [0,%d)", kNConv);
+    const int last = m->arch.n_conv - 1;
+    if (layer < 0 || layer > last) return fail(CS_ERR_INVALID, "layer must be in [0,%d]", last);
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     const int64_t ch = n < m->chunk ? n : m->chunk;
-    if ((rc = ensure_workspace(m, ch, layer == 6))) return rc;
-    const size_t fl = kLayerFloats[layer];
+    if ((rc = ensure_workspace(m, ch, layer == last))) return rc;
+    const size_t fl = m->arch.floats[layer];
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* x;
-        if ((rc = stage_in(m, crops, crops_kind, off, nc, (size_t)kH * kW, m->xin, &x))) return rc;
-        if ((rc = run_convs(m, m->ae, x, nc, 0, layer, layer == 6 ? m->recon.as<float>() : nullptr))) return rc;
-        const void* src = layer == 6 ? m->recon.p : m->act[layer].p;
+        if ((rc = stage_in(m, crops, crops_kind, off, nc, m->arch.npix, m->xin, &x))) return rc;
+        if ((rc = run_convs(m, m->ae, x, nc, 0, layer, layer == last ? m->recon.as<float>() : nullptr))) return rc;
+        const void* src = layer == last ? m->recon.p : m->act[layer].p;
         HIPCHK(hipMemcpyAsync(out + (size_t)off * fl, src, (size_t)nc * fl * sizeof(float),
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));

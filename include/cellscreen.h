@@ -122,6 +122,8 @@ typedef struct cs_model_info {
     int32_t has_detector;
     int32_t device_id;
     int64_t chunk_cells;              /* cells processed per internal pass */
+    int32_t channels[CS_MAX_CONV];    /* filters of each conv */
+    int32_t reference_arch;           /* 1: the reference graph (tuned kernels); 0: generic-shape kernels */
 } cs_model_info;
 
 /* ---- library / device ---------------------------------------------------------- */
@@ -141,7 +143,14 @@ int cs_model_load(const char *model_dir, int device_id, cs_model **out);
  * encoder:     weights of encoder.keras (:29), n_conv = n_enc convs; NULL = same as the
  *              autoencoder's encoder half.  The two files may differ
  *              (CAE_improved_modeltrain.py:270-275 vs :300).
- * detector:    may be NULL; then cs_screen returns CS_ERR_NO_DETECTOR. */
+ * detector:    may be NULL; then cs_screen returns CS_ERR_NO_DETECTOR.
+ * Architectures: the reference graph (64x64, filters 32-64-32 | 32-64-32-1) runs on kernels tuned for
+ * it.  Any other instance of the same layer grammar -- create_improved_autoencoder(input_shape) is
+ * generic in its input size (CAE_improved_modeltrain.py:184), e.g. BASELINE.json configs[4]: 128x128,
+ * filters 32-64-128 | 128-64-32-1 -- runs on run-time-shaped MFMA kernels (csrc/conv_generic.hip):
+ * n_conv = 2 n_enc + 1, last conv 1 filter, every conv grid's width a multiple of 16 and <= 128,
+ * channel counts multiples of 4.  Anything else: CS_ERR_UNSUPPORTED.  Training handles (cs_train_*)
+ * exist for the reference graph only. */
 int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights *encoder,
                          const cs_detector_params *detector, int device_id, cs_model **out);
 void cs_model_free(cs_model *m);

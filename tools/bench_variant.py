@@ -1,0 +1,26 @@
+"""Throughput of the generic-shape path on BASELINE.json configs[4] (128x128 crops, filters 32-64-128 |
+128-64-32-1; 349.18 M MAC/cell): autoencoder forward + reconstruction error,
+crops resident in HBM.  Not a bench line (bench.py is); prints one JSON object."""
+import json, sys, time
+sys.path.insert(0, "cell-image-analysis_amd")
+import numpy as np, torch
+from cellscreen import synth
+from cellscreen.engine import Engine
+
+HW, CH = (128, 128), (32, 64, 128, 128, 64, 32, 1)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+w = synth.random_cae(seed=5, hw=HW, channels=CH, n_enc=3)
+e = Engine.from_weights(w)
+x = torch.rand((n, *HW), dtype=torch.float32, device="cuda")
+e.set_chunk(4096)
+e.reconstruct(x, want_recon=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+steps = 3
+for _ in range(steps):
+    e.reconstruct(x, want_recon=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+macs = 349.18e6
+print(json.dumps({"workload": f"{n} crops 128x128, filters {CH}, CAE forward + reconstruction MSE/MAE", "cells_per_s": n / dt,
+                  "ms_per_step": dt * 1e3, "tflops_algorithmic": 2 * macs * n / dt / 1e12, "frac_fp32_mfma_peak": 2 * macs * n / dt / 157.3e12}))
