@@ -67,6 +67,16 @@ def test_bad_arguments_are_rejected_before_any_device_work():
     s = _fill_cae(w, keep)
     assert lib.cs_model_from_arrays(C.byref(s), None, None, 0, C.byref(h)) == -6  # CS_ERR_UNSUPPORTED
     assert lib.cs_model_from_arrays(None, None, None, 0, C.byref(h)) == -1       # CS_ERR_INVALID
+    # the architecture is judged before the device is touched: a non-reference instance of the layer grammar
+    # that the generic kernels cover gets as far as "no device" here; one outside the grammar is refused
+    big = synth.random_cae(seed=5, hw=(128, 128), channels=(32, 64, 128, 128, 64, 32, 1), n_enc=3)
+    rc = lib.cs_model_from_arrays(C.byref(_fill_cae(big, keep)), None, None, 0, C.byref(h))
+    assert rc == (-4 if lib.cs_device_count() <= 0 else 0)
+    if rc == 0:
+        lib.cs_model_free(h)
+    odd = synth.random_cae(seed=5, hw=(64, 64), channels=(32, 64, 32, 32, 1), n_enc=3)           # n_conv != 2 n_enc + 1
+    assert lib.cs_model_from_arrays(C.byref(_fill_cae(odd, keep)), None, None, 0, C.byref(h)) == -6
+    assert b"grammar" in lib.cs_last_error()
 
 
 def test_model_dir_round_trip(tmp_path, golden_det):
