@@ -53,22 +53,87 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
         const int ybase = g.ups ? (y0 / 2 - 1) : (y0 - 1);
 
         __syncthreads();                                  // previous item's readers are done
-        for (int e = tid; e < R * WP * cin; e += 256) {
-            const int ci = e % cin, pix = e / cin;
-            const int r = pix / WP, c = pix - r * WP;
-            const int sy = ybase + r, sx = c - 1;
-            float v = 0.0f;
-            if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = src[((size_t)sy * Ws + sx) * cin + ci];
-            strip[pix * ps + ci] = v;
+        if (cin % 4 == 0) {
+            const int c4n = cin / 4;
+            for (int e = tid; e < R * WP * c4n; e += 256) {
+                const int c4 = e % c4n, pix = e / c4n;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+                *(f32x4*)(strip + pix * ps + 4 * c4) = v;
+            }
+        } else {
+            for (int e = tid; e < R * WP * cin; e += 256) {
+                const int ci = e % cin, pix = e / cin;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                float v = 0.0f;
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = src[((size_t)sy * Ws + sx) * cin + ci];
+                strip[pix * ps + ci] = v;
+            }
         }
         __syncthreads();
 
-        const int co = (cb * 4 + wave) * 16 + li;
-        const bool live = (cb * 4 + wave) * 16 < cout;    // wave-uniform: this slice exists
+        // waves = (16-channel slice) x (tile group): with fewer than 4 slices left in this block of 64
+        // channels the spare waves split the strip's tile columns instead of idling (cout = 32: 2 x 2,
+        // cout = 1: 1 x 4); a tile and the one below it stay in the same wave (pooling)
+        const int nsl_blk = min(4, (cout - cb * 64 + 15) / 16);
+        const int nmg = nsl_blk >= 3 ? 1 : (nsl_blk == 2 ? 2 : 4);
+        const int slice = wave % (4 / nmg), mg = wave / (4 / nmg);
+        const int co = (cb * 4 + slice) * 16 + li;
+        const bool live = (cb * 4 + slice) * 16 < cout;   // wave-uniform: this slice exists
+        auto mine = [&](int t) { return ((t % TPR) & (nmg - 1)) == mg; };   // wave-uniform
         if (live) {
             f32x4 acc[TPS];
 #pragma unroll
             for (int t = 0; t < TPS; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (cin % 16 == 0) {
+                // K walked as (tap, 16-channel block, j): lane (li, kq) reads the 4 channels 16 q + 4 kq + j of its
+                // pixel with one ds_read_b128 and uses them in 4 successive MFMAs (MFMA j contracts the channels
+                // {16 q + 4 kq' + j}); the matching B rows are w[tap][16 q + 4 kq + j][co].  Per tap the tiles' LDS
+                // offsets are computed once; the next block's B values are fetched while this block's MFMAs run.
+                const int nq = cin / 16;
+                const float* wl = g.w + co;
+                const bool cok = co < cout;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    int base[TPS];
+#pragma unroll
+                    for (int t = 0; t < TPS; ++t) {
+                        const int py = t / TPR, px = (t % TPR) * 16 + li;
+                        int r, c;
+                        if (g.ups) {
+                            r = ((y0 + py + dy) >> 1) - ybase;
+                            c = ((px + dx) >> 1) + 1;
+                        } else {
+                            r = py + dy + 1;
+                            c = px + dx + 1;
+                        }
+                        base[t] = (r * WP + c) * ps + 4 * kq;
+                    }
+                    const float* wt = wl + (size_t)(tap * cin + 4 * kq) * cout;
+                    float bn[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)j * cout] : 0.0f;
+                    for (int q = 0; q < nq; ++q) {
+                        float b[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[j] = bn[j];
+                        if (q + 1 < nq) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)(16 * (q + 1) + j) * cout] : 0.0f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < TPS; ++t) {
+                            if (!mine(t)) continue;
+                            const f32x4 a = *(const f32x4*)(strip + base[t] + 16 * q);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
             const int ksteps = (9 * cin + 3) / 4;         // cin == 1: 9 -> 3 steps, zero padded
             for (int s = 0; s < ksteps; ++s) {
                 const int k = 4 * s + kq;                 // this lane's K index: k = tap * cin + ci
@@ -78,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
                 const float b = (kv && co < cout) ? g.w[((size_t)tap * cin + ci) * cout + co] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < TPS; ++t) {
+                    if (!mine(t)) continue;
                     const int py = t / TPR, px = (t % TPR) * 16 + li;
                     int r, c;
                     if (g.ups) {
@@ -91,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
                 }
             }
+            }
             // D: lane = channel li of the slice, registers = pixels 4 kq .. 4 kq + 3 of the tile
             if (co < cout) {
                 const float bias = g.ep[co];
@@ -100,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
                     for (int t = 0; t < TPS; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if (!mine(t)) continue;
                             const int py = t / TPR, px = (t % TPR) * 16 + 4 * kq + r;
                             const float z = acc[t][r] + bias;
                             o[((size_t)py * W + px) * cout + co] = 1.0f / (1.0f + expf(-z));
@@ -113,6 +181,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
                         for (int t = 0; t < TPS; ++t)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
+                                if (!mine(t)) continue;
                                 const int py = t / TPR, px = (t % TPR) * 16 + 4 * kq + r;
                                 o[((size_t)py * W + px) * cout + co] = post(acc[t][r]);
                             }
@@ -122,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
                         for (int t = 0; t < TPR; ++t)
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
+                                if (!mine(t)) continue;
                                 const float m0 = fmaxf(post(acc[t][2 * h]), post(acc[t][2 * h + 1]));
                                 const float m1 = fmaxf(post(acc[t + TPR][2 * h]), post(acc[t + TPR][2 * h + 1]));
                                 o[(size_t)(t * 8 + 2 * kq + h) * cout + co] = fmaxf(m0, m1);
