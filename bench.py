@@ -32,11 +32,13 @@ for p in (os.path.join(ROOT, "cell-image-analysis_amd"), ROOT):
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0              # spec
 FLOP_PER_CELL = 100_270_080        # ALGORITHMIC: 2 x 50,135,040 conv MACs of the reference graph, SURVEY.md section 8d
-# EXECUTED multiply-adds as a fraction of the algorithmic ones, per kernel: the three convs behind an
-# UpSampling2D are evaluated as four 2x2-tap phase convs with pre-summed weights and conv2 as a
-# Winograd F(2x2,3x3) convolution (both exact algebra, 4/9 of the MACs); conv1 pads K = 9 to 12 for
-# the 16x16x4 MFMA.
-EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0, "conv5_up_relu_bn": 4.0 / 9.0, "conv6_up_relu_bn": 4.0 / 9.0,
+# EXECUTED multiply-adds as a fraction of the algorithmic ones, per kernel (all exact algebra): conv2 and
+# conv3 are Winograd F(2x2,3x3) convolutions (4/9); the convs behind an UpSampling2D are four 2x2-tap phase
+# convs with pre-summed weights (4/9: conv7), conv5 and conv6 additionally as Winograd F(2x2,2x2) per phase
+# (9/16 of 4/9 = 1/4); conv1 pads K = 9 to 12 for the 16x16x4 MFMA.
+EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0,
+                 "conv5_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6") or os.environ.get("CS_NO_WINO5")) else 0.25,
+                 "conv6_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6")) else 0.25,
                  "conv7_up_sigmoid_err": 4.0 / 9.0,
                  "conv2_relu_bn_pool": 1.0 if os.environ.get("CS_NO_WINOGRAD") else 4.0 / 9.0,
                  "conv3_relu_bn_pool": 1.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO3")) else 4.0 / 9.0}
@@ -211,7 +213,7 @@ def main():
                            "frac_fp32_mfma_peak": round(value * FLOP_PER_CELL / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                            "tflops_executed": round(value * exec_flop_per_cell / 1e12 / world, 3),
                            "frac_fp32_mfma_peak_executed": round(value * exec_flop_per_cell / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "note": "algorithmic = the reference graph's 100.27 MFLOP/cell; executed counts the Winograd conv2 and the folded-upsample convs at 4/9",
+                           "note": "algorithmic = the reference graph's 100.27 MFLOP/cell; executed counts conv2/conv3 (Winograd F(2,3)) and conv7 (folded upsample) at 4/9, conv5/conv6 (folded + Winograd F(2,2)) at 1/4, conv1 at 12/9",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
                            "device_ms_per_step": round(total_ms / args.steps, 3)},

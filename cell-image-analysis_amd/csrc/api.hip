@@ -31,6 +31,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
+    DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
     DevBuf ep[6];          // [3][cout] bias, bn_scale, bn_shift
     int n = 0;             // number of convs packed (6 for the autoencoder, 3 for encoder.keras)
@@ -62,6 +63,8 @@ struct cs_model {
     GenSet gae, genc;
     bool shared_encoder = true;
     bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
+    bool wino6 = getenv("CS_NO_WINO6") == nullptr;         // A/B knob: conv5/conv6 folded-direct instead of F(2x2,2x2) phases
+    bool wino5 = getenv("CS_NO_WINO5") == nullptr;         // A/B knob: conv5 only
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
     DevBuf w7eff, b7;      // conv7: effective weights [16][32] and bias, on device
     // detector
@@ -206,6 +209,12 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
         }
         rc = upload(set.ep[l], ep.data(), ep.size() * sizeof(float));
         if (rc) return rc;
+        if (l == 4 || l == 5) {
+            tmp.resize(pack_wino_up_fragments(l, nullptr, nullptr));
+            pack_wino_up_fragments(l, w->kernel[l], tmp.data());
+            rc = upload(set.winoup[l], tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+        }
         if (l == 1 || l == 2) {
             tmp.resize(pack_wino_cs_fragments(l, nullptr, nullptr));
             pack_wino_cs_fragments(l, w->kernel[l], tmp.data());
@@ -371,6 +380,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     if (!m->arch.ref) return run_convs_generic(m, &set == &m->enc ? m->genc : m->gae, x, nc, first, last, recon);
     for (int l = first; l <= last && l < 6; ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
+            LAUNCH(K_CONV1 + l, nc,
+                   launch_conv_wino_up(l, in, set.winoup[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
         if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_cs(l, in, set.winocs[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));

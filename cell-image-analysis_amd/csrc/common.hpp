@@ -38,6 +38,10 @@ size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* d
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
 size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
+// conv5 (layer 4) / conv6 (layer 5), the upsample-fed decoder convs, as four Winograd F(2x2,2x2) phase convs: conv_wino_up.hip
+hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
+                               hipStream_t stream);
+size_t pack_wino_up_fragments(int layer, const float* hwio, float* dst);
 // Host-side packing of HWIO weights into the per-lane B fragments of launch_conv_mfma.
 // Returns the number of floats written (or required if dst == nullptr).
 size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);

@@ -1,0 +1,273 @@
+// conv_wino_up.hip -- conv5 and conv6 of the reference autoencoder (UpSampling2D(2x2) -> Conv2D 32->64 /
+// 64->32, 3x3 same, relu -> BatchNorm; CAE_improved_modeltrain.py:206-213) as four Winograd F(2x2, 2x2)
+// phase convs each.
+//
+// Nearest x2 upsampling makes the 3x3 taps of output pixel (2Y+a, 2X+b) land on only 2x2 STORED pixels,
+// so the layer is four phase convs (a,b) with 2x2 effective taps over the stored 16x16 grid
+// (W_eff[a][b][ry][rx] = the taps that share a stored pixel, pre-summed: the "folded" form of
+// conv_mfma.hip, 4/9 of the direct MACs).  A 2x2-tap conv producing a 2x2 block of outputs is
+// Winograd F(2x2, 2x2): 9 multiplies instead of 16 per channel pair, with
+//     B^T = [1 -1 0; 0 1 0; 0 1 -1]   G = [1 0; 1 1; 0 1]   A^T = [1 1 0; 0 1 -1]
+// (entries 0, +-1 only: the transforms add no rounding beyond one fp32 add each), so the layer
+// executes 9/16 x 4/9 = 1/4 of its direct multiply-adds.
+//
+//   V_p = B^T d_p B     3x3 patch of phase p = (a,b): stored rows 2ty+a-1 .. +2, cols 2tx+b-1 .. +2
+//   M_p,xi = V_p,xi U_p,xi   9 products [16 tiles x 64] x [64 x 16] per phase and 16-channel slice   (fp32 MFMA)
+//   Y_p = A^T M_p A     the 2x2 stored pixels of the tile -> output pixels (2(2ty+u)+a, 2(2tx+v)+b)
+//
+// A workgroup is 8 waves = 4 phases x 2 halves of the output slices; a wave keeps U_p for its slices
+// resident (conv6: 9 xi x 16 K steps x 1 slice, conv5: 9 x 8 x 2 slices = 144 VGPRs either way), transforms
+// its phase's patches in registers (each lane: its tile's 3x3 patch for its 4 channels), issues 144 MFMAs
+// per 16-tile group and finishes its own outputs: no cross-wave traffic, one barrier per group (strip
+// double buffer).  conv5's waves handle their two slices one after the other and repeat the (cheap)
+// transform, so only nine accumulators are live at a time.
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace cs {
+
+namespace {
+
+// HS x WS: stored input grid (the output grid is twice that); a 16-tile group is 16 / (WS/2) tile rows.
+template <int HS_, int WS_, int CIN_, int COUT_>
+struct WUCfg {
+    static constexpr int HS = HS_, WS = WS_, CIN = CIN_, COUT = COUT_;
+    static constexpr int HO = 2 * HS, WO = 2 * WS;
+    static constexpr int TW = WS / 2;                          // tiles per tile row (8 | 4)
+    static constexpr int SR = 2 * (16 / TW);                   // stored rows per group (4 | 8)
+    static constexpr int R = SR + 2, WP = WS + 2;
+    static constexpr int PS = CIN + 4;                         // odd number of 16-B slots per pixel
+    static constexpr int STRIP = R * WP * PS * 4;              // bytes, double buffered
+    static constexpr int LDS = 2 * STRIP;
+    static constexpr int NGRP = HS / SR;                       // groups per cell (4 | 1)
+    static constexpr int NQ = CIN / 16, KS = CIN / 4;
+    static constexpr int NSW = COUT / 32;                      // output slices per wave (8 waves = 4 phases x 2)
+    static constexpr int NB = 9 * KS * NSW;                    // B registers (144 for both layers)
+    static constexpr int C4 = CIN / 4, TOT = R * WP * C4;
+    static constexpr int THREADS = 512;
+    static constexpr int NLD = (TOT + THREADS - 1) / THREADS;
+    static_assert(NB == 144 && LDS <= 160 * 1024 && HS % SR == 0 && (NSW == 1 || NSW == 2), "layer does not fit this design");
+};
+using WUL6 = WUCfg<16, 16, 64, 32>;    // conv6: a5 16x16x64 -> a6 32x32x32
+using WUL5 = WUCfg<8, 8, 32, 64>;      // conv5: a4 8x8x32  -> a5 16x16x64
+
+template <class C>
+__device__ __forceinline__ bool wu_valid(int y0, int idx, int& sy, int& sx, int& c4)
+{
+    const int pix = idx / C::C4;
+    c4 = idx % C::C4;
+    const int r = pix / C::WP, c = pix % C::WP;
+    sy = y0 - 1 + r;
+    sx = c - 1;
+    return idx < C::TOT && sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS;
+}
+// unconditional load from a clamped address; the zero padding is applied at the LDS write
+template <class C>
+__device__ __forceinline__ f32x4 wu_load(const float* __restrict__ in, long cell, int y0, int idx)
+{
+    const float* src = in + (size_t)cell * C::HS * C::WS * C::CIN;
+    int sy, sx, c4;
+    const bool ok = wu_valid<C>(y0, idx, sy, sx, c4);
+    return *(const f32x4*)(src + (ok ? (sy * C::WS + sx) * C::CIN + c4 * 4 : 0));
+}
+template <class C>
+__device__ __forceinline__ void wu_store(float* strip, int y0, int idx, f32x4 v)
+{
+    int sy, sx, c4;
+    if (!wu_valid<C>(y0, idx, sy, sx, c4)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (idx < C::TOT) *(f32x4*)(strip + (idx / C::C4) * C::PS + c4 * 4) = v;
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float* __restrict__ in, const float* __restrict__ ufrag,
+                                                                     const float* __restrict__ ep /* [3][cout] */,
+                                                                     float* __restrict__ out, long n_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave >> 1, wsl = wave & 1;                      // phase (a,b); which half of the output slices
+    const int pa = ph >> 1, pb = ph & 1;
+    const int li = lane & 15, kq = lane >> 4;
+
+    float B[C::NB];
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) B[s] = ufrag[((size_t)wave * C::NB + s) * 64 + lane];
+    float bias[C::NSW], bns[C::NSW], bnt[C::NSW];
+#pragma unroll
+    for (int k = 0; k < C::NSW; ++k) {
+        const int co = (wsl * C::NSW + k) * 16 + li;
+        bias[k] = ep[co]; bns[k] = ep[C::COUT + co]; bnt[k] = ep[2 * C::COUT + co];
+        asm volatile("" : "+v"(bias[k]), "+v"(bns[k]), "+v"(bnt[k]));   // touch before the loop (see conv_mfma.hip)
+    }
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
+
+    // top-left of this lane's 3x3 patch inside the strip (strip row 0 = stored row y0 - 1, col 0 = -1)
+    const int trow = li / C::TW, tcol = li % C::TW;
+    const int poff = ((2 * trow + pa) * C::WP + 2 * tcol + pb) * C::PS + 4 * kq;
+
+    const long total = n_cells * C::NGRP;
+    const long first = blockIdx.x;
+    if (first >= total) return;
+#pragma unroll
+    for (int j = 0; j < C::NLD; ++j) {
+        const int idx = tid + C::THREADS * j;
+        wu_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, idx, wu_load<C>(in, first / C::NGRP, (int)(first % C::NGRP) * C::SR, idx));
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (long item = first; item < total; item += gridDim.x) {
+        const long cell = item / C::NGRP;
+        const int grp = (int)(item % C::NGRP);
+        const long nitem = item + gridDim.x;
+        const bool has_next = nitem < total;
+        const float* strip = (const float*)(smem + buf * C::STRIP);
+        float* nstrip = (float*)(smem + (buf ^ 1) * C::STRIP);
+
+        f32x4 stg[C::NLD];
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(in, nitem / C::NGRP, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j);
+        }
+
+        const float* d0 = strip + poff;
+#pragma unroll
+        for (int k = 0; k < C::NSW; ++k) {         // conv5: the wave's two slices in turn (the transform is repeated)
+            f32x4 acc[9];
+#pragma unroll
+            for (int x = 0; x < 9; ++x) acc[x] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) {
+                // W = B^T d (rows), then V[r] = W[r] B (columns), one row of V at a time.  JW channels of the
+                // lane's four at a time: conv6 (144 weight + 36 accumulator VGPRs) transforms two channels per
+                // pass (8-byte patch reads) to stay inside the 256-register budget of two waves per SIMD
+                constexpr int JW = 4;
+                typedef float fvec __attribute__((ext_vector_type(JW)));
+#pragma unroll
+                for (int jh = 0; jh < 4 / JW; ++jh) {
+                    // keep the scheduler from hoisting every pass's patch reads to the top of the group (spills)
+                    __builtin_amdgcn_sched_barrier(0);
+                    fvec w[3][3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const fvec p0 = *(const fvec*)(d0 + (0 * C::WP + c) * C::PS + 16 * q + JW * jh);
+                        const fvec p1 = *(const fvec*)(d0 + (1 * C::WP + c) * C::PS + 16 * q + JW * jh);
+                        const fvec p2 = *(const fvec*)(d0 + (2 * C::WP + c) * C::PS + 16 * q + JW * jh);
+                        w[0][c] = p0 - p1;
+                        w[1][c] = p1;
+                        w[2][c] = p1 - p2;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const fvec v[3] = {w[r][0] - w[r][1], w[r][1], w[r][1] - w[r][2]};
+#pragma unroll
+                        for (int j = 0; j < JW; ++j)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                acc[3 * r + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][j], B[(k * 9 + 3 * r + c) * C::KS + 4 * q + JW * jh + j],
+                                                                                     acc[3 * r + c], 0, 0, 0);
+                    }
+                }
+            }
+            // Y = A^T M A per tile register, bias -> relu -> BN, scatter to the phase's output pixels
+            const int co = (wsl * C::NSW + k) * 16 + li;
+            auto post = [&](float v) { v += bias[k]; v = fmaxf(v, 0.0f); return fmaf(v, bns[k], bnt[k]); };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m00 = acc[0][r], m01 = acc[1][r], m02 = acc[2][r];
+                const float m10 = acc[3][r], m11 = acc[4][r], m12 = acc[5][r];
+                const float m20 = acc[6][r], m21 = acc[7][r], m22 = acc[8][r];
+                const float t00 = m00 + m10, t01 = m01 + m11, t02 = m02 + m12;     // A^T M, row u = 0
+                const float t10 = m10 - m20, t11 = m11 - m21, t12 = m12 - m22;     //        row u = 1
+                const float y00 = t00 + t01, y01 = t01 - t02, y10 = t10 + t11, y11 = t11 - t12;
+                const int t = 4 * kq + r;                                           // tile of the group (MFMA D row)
+                const int Y = grp * C::SR + 2 * (t / C::TW), X = 2 * (t % C::TW);   // stored pixel (u = v = 0) of the tile
+                float* o = out + (((size_t)cell * C::HO + 2 * Y + pa) * C::WO + 2 * X + pb) * C::COUT + co;
+                o[0] = post(y00);                                                   // (u,v) = (0,0)
+                o[2 * C::COUT] = post(y01);                                         // (0,1): output column + 2
+                o[(size_t)2 * C::WO * C::COUT] = post(y10);                         // (1,0): output row + 2
+                o[(size_t)2 * C::WO * C::COUT + 2 * C::COUT] = post(y11);
+            }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) wu_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j, stg[j]);
+        }
+        __syncthreads();   // this strip fully read; the next strip complete in the other buffer
+        buf ^= 1;
+    }
+}
+
+// U = G W_eff G^T per (phase, cin, cout), evaluated in double and rounded once.
+// Layout [wave = phase * 2 + half][(k * 9 + xi) * KS + 4 q + j][lane]:
+//   U[xi = 3 r + c][ci = 16 q + 4 kq + j][co = 16 (half * NSW + k) + li].
+template <class C>
+size_t pack_frags(const float* hwio, float* dst)
+{
+    const size_t total = (size_t)8 * C::NB * 64;
+    if (!dst) return total;
+    static const double G[3][2] = {{1, 0}, {1, 1}, {0, 1}};
+    for (int ph = 0; ph < 4; ++ph)
+        for (int half = 0; half < 2; ++half)
+            for (int k = 0; k < C::NSW; ++k)
+                for (int xi = 0; xi < 9; ++xi)
+                    for (int kk = 0; kk < C::KS; ++kk)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int a = ph >> 1, b = ph & 1, li = lane & 15, kq = lane >> 4, q = kk >> 2, j = kk & 3;
+                            const int ci = 16 * q + 4 * kq + j, co = 16 * (half * C::NSW + k) + li, r = xi / 3, c = xi % 3;
+                            double u = 0.0;
+                            for (int ry = 0; ry < 2; ++ry)
+                                for (int rx = 0; rx < 2; ++rx) {
+                                    double weff = 0.0;   // taps (dy,dx) whose upsampled source is stored pixel (a-1+ry, b-1+rx)
+                                    for (int dy = -1; dy <= 1; ++dy)
+                                        for (int dx = -1; dx <= 1; ++dx)
+                                            if (((a + dy) >> 1) == a + ry - 1 && ((b + dx) >> 1) == b + rx - 1)
+                                                weff += (double)hwio[((size_t)((dy + 1) * 3 + (dx + 1)) * C::CIN + ci) * C::COUT + co];
+                                    u += G[r][ry] * weff * G[c][rx];
+                                }
+                            dst[((size_t)(ph * 2 + half) * C::NB + (k * 9 + xi) * C::KS + kk) * 64 + lane] = (float)u;
+                        }
+    return total;
+}
+
+template <class C>
+hipError_t launch(const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
+{
+    static int resident = 0;
+    if (!resident) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_up_kernel<C>, C::THREADS, C::LDS);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
+    }
+    const long total = (long)n_cells * C::NGRP;
+    if (total <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    hipLaunchKernelGGL(conv_wino_up_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t pack_wino_up_fragments(int layer, const float* hwio, float* dst)
+{
+    return layer == 5 ? pack_frags<WUL6>(hwio, dst) : pack_frags<WUL5>(hwio, dst);
+}
+
+hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
+                               hipStream_t stream)
+{
+    if (layer == 5) return launch<WUL6>(in, ufrag, ep, out, n_cells, stream);
+    if (layer == 4) return launch<WUL5>(in, ufrag, ep, out, n_cells, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cs
