@@ -58,6 +58,8 @@ struct ProfEvent { int kid; hipEvent_t a, b; int64_t cells; };
 struct cs_model {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;                     // host-input path: H2D of chunk i+1 while chunk i computes
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
     Arch arch;
     ConvSet ae, enc;
     GenSet gae, genc;
@@ -75,7 +77,7 @@ struct cs_model {
     // workspace (per chunk)
     int64_t chunk = 16384;
     int64_t ws_cells = 0;
-    DevBuf xin, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
+    DevBuf xin, xin2, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
     // profiling
     bool prof = false;
     std::vector<ProfEvent> pending;
@@ -85,6 +87,11 @@ struct cs_model {
     ~cs_model()
     {
         for (auto& e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (int i = 0; i < 2; ++i) {
+            if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
+            if (ev_used[i]) (void)hipEventDestroy(ev_used[i]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -495,7 +502,12 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
 #define FAIL_IF(x) do { int r__ = (x); if (r__) { delete m; return r__; } } while (0)
     {
         hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete m; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&m->ev_in[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_used[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { delete m; return fail(CS_ERR_HIP, "stream/event creation: %s", hipGetErrorString(e)); }
     }
     if (arch.ref) {
         FAIL_IF(pack_set(m->ae, autoencoder, 6));
@@ -705,33 +717,68 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_screen needs detector parameters");
     const int64_t ch = n < m->chunk ? n : m->chunk;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
-    for (int64_t off = 0; off < n; off += ch) {
+    // Host crops: two staging buffers; the H2D copy of chunk i+1 runs on its own stream while chunk i
+    // computes (PCIe at ~50 GB/s carries 3 M cells/s, so the copy hides behind the kernels).  Host results
+    // are collected on the device for the whole call and copied back once (18 B per cell).
+    const bool host_in = crops_kind == CS_MEM_HOST, host_out = out_kind == CS_MEM_HOST;
+    const size_t in_bytes = m->arch.npix * sizeof(float);
+    DevBuf* stage[2] = {&m->xin, &m->xin2};
+    if (host_in) {
+        if ((rc = m->xin.ensure((size_t)ch * in_bytes)) || (n > ch && (rc = m->xin2.ensure((size_t)ch * in_bytes)))) return rc;
+        HIPCHK(hipMemcpyAsync(m->xin.p, crops, (size_t)ch * in_bytes, hipMemcpyHostToDevice, m->copy_stream));
+        HIPCHK(hipEventRecord(m->ev_in[0], m->copy_stream));
+    }
+    if (host_out) {
+        if ((mse && (rc = m->o_mse.ensure((size_t)n * sizeof(float)))) || (mae && (rc = m->o_mae.ensure((size_t)n * sizeof(float)))) ||
+            (cons_score && (rc = m->o_sc[0].ensure((size_t)n * sizeof(double)))) || (mod_score && (rc = m->o_sc[1].ensure((size_t)n * sizeof(double)))) ||
+            (cons_pred && (rc = m->o_pr[0].ensure((size_t)n))) || (mod_pred && (rc = m->o_pr[1].ensure((size_t)n))))
+            return rc;
+    }
+    auto dst = [&](auto* user, DevBuf& tmp, int64_t off) -> decltype(user) {
+        if (!user) return nullptr;
+        return host_out ? (decltype(user))tmp.p + off : user + off;
+    };
+    int64_t i = 0;
+    for (int64_t off = 0; off < n; off += ch, ++i) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
-        const float* x;
-        if ((rc = stage_in(m, crops, crops_kind, off, nc, m->arch.npix, m->xin, &x))) return rc;
+        const int b = (int)(i & 1);
+        const float* x = crops + (size_t)off * m->arch.npix;
+        if (host_in) {
+            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_in[b], 0));
+            x = stage[b]->as<float>();
+        }
         if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, nullptr))) return rc;
         const float* feat = m->act[m->arch.n_enc - 1].as<float>();
         if (!m->shared_encoder) {
             // encoder.keras differs from the autoencoder's encoder half: second encoder pass
-            // (improved_detection.py:130), after the decoder has consumed act[2].
+            // (improved_detection.py:130), after the decoder has consumed the first pass's features.
             if ((rc = run_convs(m, m->enc, x, nc, 0, m->arch.n_enc - 1, nullptr))) return rc;
             feat = m->act[m->arch.n_enc - 1].as<float>();
         }
-        float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
-        float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
-        double* d_sc = out_ptr(cons_score, out_kind, off, m->o_sc[0]);
-        double* d_sm = out_ptr(mod_score, out_kind, off, m->o_sc[1]);
-        int8_t* d_pc = out_ptr(cons_pred, out_kind, off, m->o_pr[0]);
-        int8_t* d_pm = out_ptr(mod_pred, out_kind, off, m->o_pr[1]);
-        if ((rc = run_tail(m, feat, nc, d_mse, d_mae, d_sc, d_sm, d_pc, d_pm, true))) return rc;
-        if ((rc = stage_out(m, mse, out_kind, off, nc, d_mse))) return rc;
-        if ((rc = stage_out(m, mae, out_kind, off, nc, d_mae))) return rc;
-        if ((rc = stage_out(m, cons_score, out_kind, off, nc, d_sc))) return rc;
-        if ((rc = stage_out(m, mod_score, out_kind, off, nc, d_sm))) return rc;
-        if ((rc = stage_out(m, cons_pred, out_kind, off, nc, d_pc))) return rc;
-        if ((rc = stage_out(m, mod_pred, out_kind, off, nc, d_pm))) return rc;
-        if (crops_kind == CS_MEM_HOST || out_kind == CS_MEM_HOST) HIPCHK(hipStreamSynchronize(m->stream));
+        if ((rc = run_tail(m, feat, nc, dst(mse, m->o_mse, off), dst(mae, m->o_mae, off), dst(cons_score, m->o_sc[0], off),
+                           dst(mod_score, m->o_sc[1], off), dst(cons_pred, m->o_pr[0], off), dst(mod_pred, m->o_pr[1], off), true)))
+            return rc;
+        if (host_in) {
+            HIPCHK(hipEventRecord(m->ev_used[b], m->stream));
+            const int64_t noff = off + ch;
+            if (noff < n) {   // next chunk into the other buffer, once the chunk before this one has released it
+                const int64_t nn = (n - noff) < ch ? (n - noff) : ch;
+                if (i >= 1) HIPCHK(hipStreamWaitEvent(m->copy_stream, m->ev_used[b ^ 1], 0));
+                HIPCHK(hipMemcpyAsync(stage[b ^ 1]->p, crops + (size_t)noff * m->arch.npix, (size_t)nn * in_bytes, hipMemcpyHostToDevice,
+                                      m->copy_stream));
+                HIPCHK(hipEventRecord(m->ev_in[b ^ 1], m->copy_stream));
+            }
+        }
     }
+    if (host_out) {
+        if (mse) HIPCHK(hipMemcpyAsync(mse, m->o_mse.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (mae) HIPCHK(hipMemcpyAsync(mae, m->o_mae.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (cons_score) HIPCHK(hipMemcpyAsync(cons_score, m->o_sc[0].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        if (mod_score) HIPCHK(hipMemcpyAsync(mod_score, m->o_sc[1].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        if (cons_pred) HIPCHK(hipMemcpyAsync(cons_pred, m->o_pr[0].p, (size_t)n, hipMemcpyDeviceToHost, m->stream));
+        if (mod_pred) HIPCHK(hipMemcpyAsync(mod_pred, m->o_pr[1].p, (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    }
+    if (host_in) HIPCHK(hipStreamSynchronize(m->copy_stream));
     return end_call(m);
 }
 

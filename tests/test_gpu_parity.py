@@ -107,6 +107,24 @@ def test_screen_end_to_end_against_oracle(engine, weights, det, crops):
     print("labels within tolerance of 0 (not compared):", skipped)
 
 
+def test_host_input_pipeline_is_chunk_invariant(engine, crops):
+    """Host crops go through two staging buffers with the copy of chunk i+1 overlapping the kernels of
+    chunk i; any chunking must give the same bits as one pass, for host and device inputs alike."""
+    import torch
+    whole = engine.screen(crops)
+    try:
+        for chunk in (1, 5, 16, 47):
+            engine.set_chunk(chunk)
+            part = engine.screen(crops)
+            for k in whole:
+                assert np.array_equal(part[k], whole[k]), f"chunk {chunk}: {k}"
+        dev = engine.screen(torch.from_numpy(crops).cuda())
+        for k in whole:
+            assert np.array_equal(dev[k].cpu().numpy(), whole[k]), f"device input: {k}"
+    finally:
+        engine.set_chunk(16384)
+
+
 def test_separate_encoder_weight_set(weights, det, crops):
     """encoder.keras != autoencoder's encoder half (CAE...:270-275 vs :300): features must come
     from the encoder set, reconstruction errors from the autoencoder set."""
