@@ -73,7 +73,7 @@ struct cs_model {
     bool has_det = false;
     int F = 0, fpad = 0, C = 0, cpad = 0;
     DevBuf center, scale, comps, mean_proj;
-    struct Svm { DevBuf sv, svT, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
+    struct Svm { DevBuf svT, svn, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
     // workspace (per chunk)
     int64_t chunk = 16384;
     int64_t ws_cells = 0;
@@ -278,17 +278,22 @@ static int pack_svm(cs_model::Svm& s, const cs_ocsvm_params& p, int D, const cha
     s.nsv_pad = (p.n_sv + 255) / 256 * 256;
     s.gamma = p.gamma;
     s.rho = p.rho;
-    std::vector<double> sv((size_t)D * s.nsv_pad, 0.0), svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0);
+    std::vector<double> svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0), svn(s.nsv_pad, 0.0);
     for (int i = 0; i < p.n_sv; ++i) {
         coef[i] = p.dual_coef[i];
+        double nn = 0.0;
         for (int d = 0; d < D; ++d) {
-            sv[(size_t)i * D + d] = p.support_vectors[(size_t)i * D + d];
-            svT[(size_t)d * s.nsv_pad + i] = p.support_vectors[(size_t)i * D + d];
+            const double v = p.support_vectors[(size_t)i * D + d];
+            svT[(size_t)d * s.nsv_pad + i] = v;
+            nn = fma(v, v, nn);
         }
+        svn[i] = nn;
     }
-    int rc = upload(s.sv, sv.data(), sv.size() * sizeof(double));
-    if (rc) return rc;
-    rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
+    {
+        int rcn = upload(s.svn, svn.data(), svn.size() * sizeof(double));
+        if (rcn) return rcn;
+    }
+    int rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
     if (rc) return rc;
     return upload(s.coef, coef.data(), coef.size() * sizeof(double));
 }
@@ -696,9 +701,8 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
                              m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
     for (int d = 0; d < 2; ++d)
         LAUNCH(K_SVM, nc,
-               launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].sv.as<double>(), m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(),
-                            m->svm[d].nsv, m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho,
-                            m->dec[d].as<double>(), nc, m->stream));
+               launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
+                            m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
     LAUNCH(K_FINALIZE, nc,
            launch_finalize(with_err ? m->errpart.as<float>() : nullptr, 4, (int)m->arch.npix, m->dec[0].as<double>(),
                            m->dec[1].as<double>(), mse, mae, sc, sm, pc, pm, nc, m->stream));
@@ -910,7 +914,7 @@ int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, doubl
         for (int d = 0; d < 2; ++d) {
             if (!outs[d]) continue;
             LAUNCH(K_SVM, nc,
-                   launch_ocsvm(p, m->C, m->svm[d].sv.as<double>(), m->svm[d].svT.as<double>(), m->svm[d].coef.as<double>(), m->svm[d].nsv,
+                   launch_ocsvm(p, m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
                                 m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
             HIPCHK(hipMemcpyAsync(outs[d] + off, m->dec[d].p, (size_t)nc * sizeof(double),
                                   out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));

@@ -101,9 +101,8 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
 
 // One-class SVM decision for one detector.  sv: [nsv_pad][D] row-major, svT: [D][nsv_pad]
 // (transposed), coef: [nsv_pad]; all zero padded.  dec[n] = sum - rho.
-hipError_t launch_ocsvm(const float* pca, int D, const double* sv, const double* svT, const double* coef,
-                        int nsv, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
-                        hipStream_t stream);
+hipError_t launch_ocsvm(const float* pca, int D, const double* svT /* [D][nsv_pad] */, const double* svn /* ||sv||^2 */,
+                        const double* coef, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells, hipStream_t stream);
 
 // errpart -> mse/mae ; dec -> score (= -dec) and pred.
 hipError_t launch_finalize(const float* errpart, int nparts, int npix, const double* dec_c,

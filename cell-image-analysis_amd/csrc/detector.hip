@@ -92,115 +92,123 @@ __global__ __launch_bounds__(256) void scaler_pca_kernel(
     }
 }
 
-// ---------------------------------------------------------------- one-class SVM decision
-// fp64 throughout (libsvm is double).  Lane <-> cell: a lane keeps its cell's D coordinates as
-// doubles in registers; support vectors are wave-uniform and arrive through scalar loads, so
-// the inner loop is two fp64 VALU instructions per (cell, sv, coordinate) and nothing else.
-// The eight waves of a workgroup share 64 cells and each walk an eighth of the support
-// vectors; their partial sums are added in wave order (deterministic).
-constexpr int SVMR_WAVES = 8;   // waves per workgroup = ways the support vectors are split
+// ---------------------------------------------------------------- one-class SVM decision (fp64 MFMA)
+// ||x - s||^2 = ||x||^2 + ||s||^2 - 2 x.s: the cross terms of 16 cells x 16 support vectors are one
+// v_mfma_f64_16x16x4_f64 chain over the D components (libsvm evaluates the kernel in double; so does
+// this, the expansion costs ~1e-16 * (||x||^2 + ||s||^2) absolute on the distance, far inside the 1e-9
+// tolerance on the decision).  A wave keeps the A fragments of two 16-cell tiles resident (2 x KS doubles);
+// the workgroup's eight waves (256 cells) share each block of 16 support vectors, staged once in LDS
+// (double buffered, one barrier per block) together with the block's ||s||^2 and dual coefficients;
+// exp() and the coefficient-weighted sum run on the accumulator layout (lane = support vector, register
+// = cell) and are reduced over the 16 lanes of a row at the end, in fixed order.
+// f64 MFMA maps: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], D[row = (l >> 4) + 4 reg][col = l & 15].
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int SVMM_WAVES = 8, SVMM_TILES = 2, SVMM_CELLS = SVMM_WAVES * SVMM_TILES * 16;
 
-template <int D>
-__global__ __launch_bounds__(64 * SVMR_WAVES, 2) void ocsvm_reg_kernel(
-    const float* __restrict__ pca, const double* __restrict__ sv /* [nsv_pad][D], zero padded */,
-    const double* __restrict__ coef /* [nsv_pad], zero padded */, int nsv, double gamma, double rho,
-    double* __restrict__ dec, long n)
+template <int KS>   // K steps of 4 components: D <= 4 KS
+__global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
+    const float* __restrict__ pca, int D, const double* __restrict__ svT /* [D][nsv_pad] */,
+    const double* __restrict__ svn /* [nsv_pad] ||s||^2 */, const double* __restrict__ coef /* [nsv_pad] */, int nsv_pad,
+    double gamma, double rho, double* __restrict__ dec, long n)
 {
-    __shared__ double part[SVMR_WAVES][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long cell = (long)blockIdx.x * 64 + lane;
-    double x[D];
+    constexpr int ROWS = 4 * KS + 2;                     // components (zero padded) + ||s||^2 row + coef row
+    __shared__ double sb[2][ROWS][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const long cell0 = (long)blockIdx.x * SVMM_CELLS + wave * (SVMM_TILES * 16);
+
+    double xa[SVMM_TILES][KS];
+    double rown[SVMM_TILES][4];
+#pragma unroll
+    for (int t = 0; t < SVMM_TILES; ++t) {
+        long cell = cell0 + t * 16 + li;
+        if (cell >= n) cell = n - 1;                     // tail rows recompute the last cell, never stored
+        double nx = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int d = 4 * s + kq;
+            const double v = d < D ? (double)pca[cell * D + d] : 0.0;
+            xa[t][s] = v;
+            nx = fma(v, v, nx);
+        }
+        nx += __shfl_xor(nx, 16);
+        nx += __shfl_xor(nx, 32);                        // every lane: ||x||^2 of cell li of the tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rown[t][r] = __shfl(nx, kq + 4 * r);   // D row (kq + 4 r) <- lane li' = kq + 4 r
+    }
+
+    // staging of one block: ROWS x 16 doubles, thread e -> (row, col)
+    constexpr int NST = (ROWS * 16 + 64 * SVMM_WAVES - 1) / (64 * SVMM_WAVES);
+    auto fetch = [&](int blk, double v[NST]) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int e = tid + 64 * SVMM_WAVES * j, row = e >> 4, col = e & 15;
+            const size_t sidx = (size_t)blk * 16 + col;
+            double x = 0.0;
+            if (row < D) x = svT[(size_t)row * nsv_pad + sidx];
+            else if (row == 4 * KS) x = svn[sidx];
+            else if (row == 4 * KS + 1) x = coef[sidx];
+            v[j] = x;
+        }
+    };
+    auto stash = [&](int buf, const double v[NST]) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int e = tid + 64 * SVMM_WAVES * j;
+            if (e < ROWS * 16) sb[buf][e >> 4][e & 15] = v[j];
+        }
+    };
+    const int nblk = nsv_pad / 16;
     {
-        const long src = cell < n ? cell : n - 1;   // tail lanes recompute the last cell, never stored
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = (double)pca[src * D + d];
+        double v[NST];
+        fetch(0, v);
+        stash(0, v);
     }
-    // support vectors are walked two at a time (rows 2j, 2j+1 of the zero-padded table: a padded
-    // row has coef 0), each distance split into two independent fma chains: four chains in
-    // flight hide the fp64 fma latency and let the two rows' scalar loads overlap.
-    const int npair = (nsv + 1) / 2;
-    const int per = (npair + SVMR_WAVES - 1) / SVMR_WAVES;
-    const int j0 = wave * per, j1 = (j0 + per < npair) ? j0 + per : npair;
-    double sum = 0.0;
-    for (int j = j0; j < j1; ++j) {
-        const double* __restrict__ s0 = sv + (size_t)(2 * j) * D;   // wave-uniform -> scalar loads
-        const double* __restrict__ s1 = s0 + D;
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    __syncthreads();
+
+    double sum[SVMM_TILES][4];
 #pragma unroll
-        for (int d = 0; d < D; d += 2) {
-            const double e0 = x[d] - s0[d], e1 = x[d + 1] - s0[d + 1];
-            const double f0 = x[d] - s1[d], f1 = x[d + 1] - s1[d + 1];
-            a0 = fma(e0, e0, a0); a1 = fma(e1, e1, a1);
-            b0 = fma(f0, f0, b0); b1 = fma(f1, f1, b1);
+    for (int t = 0; t < SVMM_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[t][r] = 0.0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        double nv[NST];
+        if (blk + 1 < nblk) fetch(blk + 1, nv);
+        f64x4 acc[SVMM_TILES];
+#pragma unroll
+        for (int t = 0; t < SVMM_TILES; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double b = sb[cur][4 * s + kq][li];
+#pragma unroll
+            for (int t = 0; t < SVMM_TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t][s], b, acc[t], 0, 0, 0);
         }
-        sum += coef[2 * j] * exp(-gamma * (a0 + a1));
-        sum += coef[2 * j + 1] * exp(-gamma * (b0 + b1));
-    }
-    part[wave][lane] = sum;
-    __syncthreads();
-    if (wave == 0 && cell < n) {
-        double t = part[0][lane];
+        const double sn = sb[cur][4 * KS][li], cf = sb[cur][4 * KS + 1][li];
 #pragma unroll
-        for (int w = 1; w < SVMR_WAVES; ++w) t += part[w][lane];
-        dec[cell] = t - rho;
-    }
-}
-
-// Generic-D fallback (D <= 128): lane <-> support vector, 16 cells per workgroup in LDS.
-constexpr int SVM_CELLS = 16;
-constexpr int SVM_MAXD = 128;
-
-__global__ __launch_bounds__(256) void ocsvm_kernel(
-    const float* __restrict__ pca, int D, const double* __restrict__ svT,
-    const double* __restrict__ coef, int nsv_pad, double gamma, double rho,
-    double* __restrict__ dec, long n)
-{
-    __shared__ double xs[SVM_CELLS * SVM_MAXD];
-    __shared__ double red[SVM_CELLS][4];
-    const int tid = threadIdx.x;
-    const long cell0 = (long)blockIdx.x * SVM_CELLS;
-    for (int idx = tid; idx < SVM_CELLS * D; idx += 256) {
-        const int c = idx / D, d = idx % D;
-        const long cell = cell0 + c;
-        xs[c * D + d] = (cell < n) ? (double)pca[cell * D + d] : 0.0;
-    }
-    __syncthreads();
-
-    double part[SVM_CELLS];
+        for (int t = 0; t < SVMM_TILES; ++t)
 #pragma unroll
-    for (int c = 0; c < SVM_CELLS; ++c) part[c] = 0.0;
-
-    for (int i = tid; i < nsv_pad; i += 256) {
-        double d2[SVM_CELLS];
-#pragma unroll
-        for (int c = 0; c < SVM_CELLS; ++c) d2[c] = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double s = svT[(size_t)d * nsv_pad + i];
-#pragma unroll
-            for (int c = 0; c < SVM_CELLS; ++c) {
-                const double diff = xs[c * D + d] - s;
-                d2[c] = fma(diff, diff, d2[c]);
+            for (int r = 0; r < 4; ++r) {
+                const double d2 = fma(-2.0, acc[t][r], rown[t][r] + sn);
+                sum[t][r] = fma(cf, exp(-gamma * d2), sum[t][r]);
             }
+        if (blk + 1 < nblk) stash(cur ^ 1, nv);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < SVMM_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = sum[t][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            const long cell = cell0 + t * 16 + kq + 4 * r;
+            if (li == 0 && cell < n) dec[cell] = v - rho;
         }
-        const double a = coef[i];
-#pragma unroll
-        for (int c = 0; c < SVM_CELLS; ++c) part[c] += a * exp(-gamma * d2[c]);
-    }
-
-#pragma unroll
-    for (int c = 0; c < SVM_CELLS; ++c) {
-        double v = part[c];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) red[c][tid >> 6] = v;
-    }
-    __syncthreads();
-    if (tid < SVM_CELLS) {
-        const long cell = cell0 + tid;
-        if (cell < n) dec[cell] = ((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3])) - rho;
-    }
 }
+
 
 // ---------------------------------------------------------------- finalize
 __global__ void finalize_kernel(const float* __restrict__ errpart, int nparts, int npix,
@@ -273,21 +281,18 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
     return hipGetLastError();
 }
 
-hipError_t launch_ocsvm(const float* pca, int D, const double* sv, const double* svT, const double* coef,
-                        int nsv, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells,
-                        hipStream_t stream)
+hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* svn, const double* coef, int nsv_pad, double gamma,
+                        double rho, double* dec, int64_t n_cells, hipStream_t stream)
 {
     if (n_cells <= 0) return hipSuccess;
-    if (D == 100) {   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
-        const unsigned grid = (unsigned)((n_cells + 63) / 64);
-        hipLaunchKernelGGL(ocsvm_reg_kernel<100>, dim3(grid), dim3(64 * SVMR_WAVES), 0, stream, pca, sv, coef, nsv, gamma, rho,
-                           dec, (long)n_cells);
-        return hipGetLastError();
-    }
-    if (D > SVM_MAXD || nsv_pad % 256) return hipErrorInvalidValue;
-    const unsigned grid = (unsigned)((n_cells + SVM_CELLS - 1) / SVM_CELLS);
-    hipLaunchKernelGGL(ocsvm_kernel, dim3(grid), dim3(256), 0, stream, pca, D, svT, coef, nsv_pad, gamma,
-                       rho, dec, (long)n_cells);
+    if (!svT || !svn || !coef || D < 1 || D > 128 || nsv_pad % 16) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_cells + SVMM_CELLS - 1) / SVMM_CELLS);
+    if (D <= 100)   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
+        hipLaunchKernelGGL(ocsvm_mfma_kernel<25>, dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
+                           rho, dec, (long)n_cells);
+    else
+        hipLaunchKernelGGL(ocsvm_mfma_kernel<32>, dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
+                           rho, dec, (long)n_cells);
     return hipGetLastError();
 }
 
