@@ -402,19 +402,22 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 tile_pixel<C>(t0, 4 * kq, qy, qx);
                 const int yo = (y0 + qy) >> 1;
                 const int xo = qx >> 1;
-                float e0[4], e1[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e0[r] = post(acc0[r]);
-                    e1[r] = post(acc1[r]);
-                }
                 float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
                 if constexpr (C::EPI == EPI_SUMPOOL) {
-                    o[0] = (e0[0] + e0[1]) + (e1[0] + e1[1]);
-                    o[C::COUT] = (e0[2] + e0[3]) + (e1[2] + e1[3]);
+                    o[0] = (acc0[0] + acc0[1]) + (acc1[0] + acc1[1]);
+                    o[C::COUT] = (acc0[2] + acc0[3]) + (acc1[2] + acc1[3]);
                 } else {
-                    o[0] = fmaxf(fmaxf(e0[0], e0[1]), fmaxf(e1[0], e1[1]));
-                    o[C::COUT] = fmaxf(fmaxf(e0[2], e0[3]), fmaxf(e1[2], e1[3]));
+                    // MaxPooling2D after bias -> ReLU -> BN: that map is monotone (non-decreasing where the BN
+                    // scale is >= 0, non-increasing where it is negative), so the max over the window of the
+                    // mapped values is the map of the window's max (resp. min) of the raw sums -- the same bits
+                    // for a third of the epilogue's VALU work
+                    const bool up = bns >= 0.0f;
+                    auto ext = [&](float a, float b, float c, float d) {
+                        const float mx = fmaxf(fmaxf(a, b), fmaxf(c, d)), mn = fminf(fminf(a, b), fminf(c, d));
+                        return up ? mx : mn;
+                    };
+                    o[0] = post(ext(acc0[0], acc0[1], acc1[0], acc1[1]));
+                    o[C::COUT] = post(ext(acc0[2], acc0[3], acc1[2], acc1[3]));
                 }
             } else {
 #pragma unroll

@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
                 a = rbase ? y00[2 + rr] : y00[rr]; b = rbase ? y01[2 + rr] : y01[rr];
                 c2 = rbase ? y10[2 + rr] : y10[rr]; d = rbase ? y11[2 + rr] : y11[rr];
             }
-            const float res = fmaxf(fmaxf(post(a), post(b)), fmaxf(post(c2), post(d)));
+            // the epilogue map is monotone (direction = sign of the BN scale): pool the raw values, map once
+            const float mx = fmaxf(fmaxf(a, b), fmaxf(c2, d)), mn = fminf(fminf(a, b), fminf(c2, d));
+            const float res = post(bns >= 0.0f ? mx : mn);
             const int t = 4 * kq + rbase + rr;                        // tile of the group (MFMA D row)
             const int ty = grp * C::TR + t / C::TW, tx = t % C::TW;
             out[(((size_t)cell * (C::H / 2) + ty) * (C::W / 2) + tx) * C::COUT + co] = res;
