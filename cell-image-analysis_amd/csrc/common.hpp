@@ -55,7 +55,9 @@ hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_d
 void conv7_effective_weights(const float* w7_hwio, float* weff);
 
 // ---- training (train.hip, conv_mfma.hip) -----------------------------------------------
-constexpr int TRAIN_MAX_PARTS = 256;   // workgroups (= partial sums) per reduction
+constexpr int TRAIN_MAX_PARTS = 256;   // workgroups (= partial sums) per weight-gradient reduction
+constexpr int BN_MAX_PARTS = 1024;     // workgroups per BatchNorm statistics / backward pass: these kernels stream whole
+                                       // tensors with ~1 element in flight per thread, so they need every SIMD several waves deep
 struct ReduceDesc { long dst; long len; const float* src; int nparts; long stride; };
 hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag, const float* bias,
                                  float* relu_out, int64_t n_cells, hipStream_t stream);

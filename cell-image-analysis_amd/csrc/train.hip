@@ -55,12 +55,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 // bn_apply / the backward pass and updates the moving statistics
 // (moving = moving*momentum + batch*(1-momentum)).  Merging inside every workgroup of
 // bn_apply cost 20 us per layer (G dependent L2 round trips on each CU).
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part, int G, int C, float eps,
-                                                             float momentum, float* __restrict__ mov_mean,
-                                                             float* __restrict__ mov_var, float* __restrict__ stats)
+constexpr int BNF_THREADS = 1024;   // one workgroup merges up to BN_MAX_PARTS partials: many short merge chains
+
+__global__ __launch_bounds__(BNF_THREADS) void bn_stats_final_kernel(const float* __restrict__ part, int G, int C, float eps,
+                                                                     float momentum, float* __restrict__ mov_mean,
+                                                                     float* __restrict__ mov_var, float* __restrict__ stats)
 {
-    __shared__ double sn[256], smu[256], sM2[256];
-    const int tid = threadIdx.x, c = tid % C, grp = tid / C, NG = 256 / C;
+    __shared__ double sn[BNF_THREADS], smu[BNF_THREADS], sM2[BNF_THREADS];
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C, NG = BNF_THREADS / C;
     const int g0 = (G * grp) / NG, g1 = (G * (grp + 1)) / NG;
     double n = 0.0, mu = 0.0, M2 = 0.0;
 #pragma unroll 4
@@ -434,11 +436,16 @@ hipError_t launch_wg(const float* xin, const float* dz, float* part, int64_t n_c
     return hipGetLastError();
 }
 
+// Strip heights of the two edge-layer weight-gradient kernels: at batch 32 a workgroup per 8 conv rows gives 256
+// workgroups (TRAIN_MAX_PARTS); these kernels are one global load per 9 FMAs, so they live on parallelism.
+constexpr int WGF_SR = 8;     // conv1: conv rows per item
+constexpr int WGL_SRS = 4;    // conv7: stored a6 rows per item (8 output rows)
+
 // conv1 (cin = 1): dW[tap][co] = sum x[y+dy][x+dx] * dz[y][x][co].  Thread = (co, pixel lane).
 __global__ __launch_bounds__(256) void wgrad_first_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                           float* __restrict__ part /*[G][9][32]*/, long n_cells)
 {
-    constexpr int H = 64, W = 64, CO = 32, SR = 16, WP = W + 2, R = SR + 2;
+    constexpr int H = 64, W = 64, CO = 32, SR = WGF_SR, WP = W + 2, R = SR + 2;
     __shared__ float xs[R * WP];
     __shared__ float red[256];
     const int tid = threadIdx.x, co = tid & 31, lane = tid >> 5;
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(const float* __restric
             xs[idx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(cell * H + sy) * W + sx] : 0.0f;
         }
         __syncthreads();
+#pragma unroll 4
         for (int p = lane; p < SR * W; p += 8) {
             const int y = p / W, xx = p % W;
             const float d = dz[((cell * H + y0 + y) * W + xx) * CO + co];
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(const float* __restric
 __global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict__ a6, const float* __restrict__ dz7,
                                                          float* __restrict__ part /*[G][9][32]*/, long n_cells)
 {
-    constexpr int HS = 32, WS = 32, CI = 32, SRS = 8, WP = WS + 2, R = SRS + 2, PS = CI + 1;
+    constexpr int HS = 32, WS = 32, CI = 32, SRS = WGL_SRS, WP = WS + 2, R = SRS + 2, PS = CI + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* as = (float*)smem;                 // [R][WP][PS]
     float* red = as + R * WP * PS;            // [256]
@@ -499,6 +507,7 @@ __global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict
         }
         __syncthreads();
         const int Y0 = 2 * ys0;
+#pragma unroll 4
         for (int p = lane; p < 2 * SRS * 64; p += 8) {
             const int Yl = p / 64, X = p % 64;      // output pixel (Y0 + Yl, X)
             const float d = dz7[(cell * 64 + Y0 + Yl) * 64 + X];
@@ -606,7 +615,7 @@ __global__ void pack_ep_kernel(const float* __restrict__ bias, const float* __re
 }  // namespace
 
 // ============================================================== launchers
-static int stat_grid(long P) { long g = P / 512; if (g < 1) g = 1; if (g > TRAIN_MAX_PARTS) g = TRAIN_MAX_PARTS; return (int)g; }
+static int stat_grid(long P) { long g = P / 128; if (g < 1) g = 1; if (g > BN_MAX_PARTS) g = BN_MAX_PARTS; return (int)g; }
 
 hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s)
 {
@@ -619,7 +628,7 @@ hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, h
 hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, float momentum, float* mov_mean,
                                  float* mov_var, float* stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, s, part, G, C, eps, momentum, mov_mean, mov_var, stats);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(BNF_THREADS), 0, s, part, G, C, eps, momentum, mov_mean, mov_var, stats);
     return hipGetLastError();
 }
 
@@ -678,7 +687,7 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
     const int mp = TRAIN_MAX_PARTS;
     switch (layer) {
         case 0: {
-            const long total = n_cells * 4;
+            const long total = n_cells * (64 / WGF_SR);
             *nparts = (int)(total < mp ? total : mp);
             hipLaunchKernelGGL(wgrad_first_kernel, dim3(*nparts), dim3(256), 0, s, xin, dz, part, (long)n_cells);
             return hipGetLastError();
@@ -689,9 +698,9 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
         case 4: return launch_wg<WgL5>(xin, dz, part, n_cells, mp, nparts, s);
         case 5: return launch_wg<WgL6>(xin, dz, part, n_cells, mp, nparts, s);
         case 6: {
-            const long total = n_cells * 4;
+            const long total = n_cells * (32 / WGL_SRS);
             *nparts = (int)(total < mp ? total : mp);
-            const int lds = (10 * 34 * 33 + 256) * 4;
+            const int lds = ((WGL_SRS + 2) * 34 * 33 + 256) * 4;
             hipLaunchKernelGGL(wgrad_last_kernel, dim3(*nparts), dim3(256), lds, s, xin, dz, part, (long)n_cells);
             return hipGetLastError();
         }

@@ -140,11 +140,11 @@ int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int dev
     for (int l = 1; l < 7; ++l)   // backward-data fragments: effective conv (cin' = cout, cout' = cin)
         TFAIL(t->wft[l].ensure(pack_conv_fragments(kRefChannels[l], cin_of(l), nullptr, nullptr) * 4));
     TFAIL(t->w7eff.ensure(16 * 32 * 4));
-    TFAIL(t->part_stats.ensure((size_t)TRAIN_MAX_PARTS * 3 * 64 * 4));
-    TFAIL(t->part_bwd.ensure((size_t)TRAIN_MAX_PARTS * 2 * 64 * 4));
+    TFAIL(t->part_stats.ensure((size_t)BN_MAX_PARTS * 3 * 64 * 4));
+    TFAIL(t->part_bwd.ensure((size_t)BN_MAX_PARTS * 2 * 64 * 4));
     TFAIL(t->bwd_sums.ensure(2 * 64 * 4));
     for (int l = 0; l < 7; ++l) {
-        TFAIL(t->dzsum_part[l].ensure((size_t)TRAIN_MAX_PARTS * 64 * 4));
+        TFAIL(t->dzsum_part[l].ensure((size_t)BN_MAX_PARTS * 64 * 4));
         TFAIL(t->wpart[l].ensure((size_t)TRAIN_MAX_PARTS * 9 * cin_of(l) * kRefChannels[l] * 4));
     }
     TFAIL(t->descs.ensure(14 * sizeof(ReduceDesc)));
