@@ -131,3 +131,35 @@ def test_device_resident_in_and_out_feeds_the_screening_path(proc):
         e.close()
     ms, px = proc.last_timing()
     assert ms > 0 and px == pix.size
+
+
+def test_raw_crops_to_flags_end_to_end(proc):
+    """improved_detection.py:98-99 -> :117-153 on the device (crops stay in HBM between cs_preprocess and
+    cs_screen) against the CPU chain preprocess oracle -> CAE/detector oracle."""
+    import torch
+    import helpers as H
+    from cellscreen.detector_fit import fit_detector
+    from cellscreen.engine import Engine
+    from oracle import oracle
+    w = synth.random_cae(seed=42)
+    raw_fit = synth.raw_crops(51, 400, np.uint16, 24, 90)
+    raw = synth.raw_crops(52, 48, np.uint16, 16, 120, flat_every=7)
+    e0 = Engine.from_weights(w)
+    det, _ = fit_detector(e0.encode(proc(raw_fit), which=0), pca_random_state=0)
+    e0.close()
+    pix, off, hs, ws = pp.pack_crops(raw)
+    d_out = torch.empty((len(raw), 64, 64), dtype=torch.float32, device="cuda")
+    proc.run_packed(torch.from_numpy(pix.view(np.int16)).cuda(), off, hs, ws, out=d_out)
+    e = Engine.from_weights(w, None, det)
+    try:
+        r = {k: v.cpu().numpy() for k, v in e.screen(d_out).items()}
+    finally:
+        e.close()
+    x_ref = po.preprocess_crops(raw)
+    assert np.abs(d_out.cpu().numpy() - x_ref).max() <= TOL_OUT
+    ref = oracle.screen(w, None, det, x_ref, acc64=True)
+    H.assert_rel(r["mse"], ref["mse"], H.TOL_ERR_REL, "mse")
+    for name, p in (("cons", det.conservative), ("mod", det.moderate)):
+        tol = H.TOL_DEC_E2E * np.abs(p.dual_coef).sum()
+        assert np.abs(r[f"{name}_score"] - ref[f"{name}_score"]).max() <= tol, name
+        H.flags_agree(-r[f"{name}_score"], r[f"{name}_pred"], ref[f"{name}_dec"], ref[f"{name}_pred"], tol, name)
