@@ -79,11 +79,24 @@ __device__ __forceinline__ void wu_store(float* strip, int y0, int idx, f32x4 v)
     if (idx < C::TOT) *(f32x4*)(strip + (idx / C::C4) * C::PS + c4 * 4) = v;
 }
 
-template <class C>
+// DIAG: diagnostic build, s_memtime stamps summed per wave: [0] next-strip load issue, [1] transforms + MFMAs,
+// [2] output transform + epilogue + stores, [3] next-strip LDS writes, [4] barrier.  Never used for results or timing.
+__device__ __forceinline__ unsigned long long wu_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <class C, bool DIAG>
 __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float* __restrict__ in, const float* __restrict__ ufrag,
                                                                      const float* __restrict__ ep /* [3][cout] */,
-                                                                     float* __restrict__ out, long n_cells)
+                                                                     float* __restrict__ out, long n_cells,
+                                                                     unsigned long long* __restrict__ diag)
 {
+    unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,11 +140,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
         const float* strip = (const float*)(smem + buf * C::STRIP);
         float* nstrip = (float*)(smem + (buf ^ 1) * C::STRIP);
 
+        if constexpr (DIAG) dt = wu_stamp();
         f32x4 stg[C::NLD];
         if (has_next) {
 #pragma unroll
             for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(in, nitem / C::NGRP, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j);
         }
+        if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[0] += t - dt; dt = t; }
 
         const float* d0 = strip + poff;
 #pragma unroll
@@ -172,6 +187,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
                     }
                 }
             }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(acc[0][0]), "v"(acc[8][3]));
+                const unsigned long long t = wu_stamp(); dg[1] += t - dt; dt = t;
+            }
             // Y = A^T M A per tile register, bias -> relu -> BN, scatter to the phase's output pixels
             const int co = (wsl * C::NSW + k) * 16 + li;
             auto post = [&](float v) { v += bias[k]; v = fmaxf(v, 0.0f); return fmaf(v, bns[k], bnt[k]); };
@@ -191,13 +210,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
                 o[(size_t)2 * C::WO * C::COUT] = post(y10);                         // (1,0): output row + 2
                 o[(size_t)2 * C::WO * C::COUT + 2 * C::COUT] = post(y11);
             }
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[2] += t - dt; dt = t; }
         }
         if (has_next) {
 #pragma unroll
             for (int j = 0; j < C::NLD; ++j) wu_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j, stg[j]);
         }
+        if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
         __syncthreads();   // this strip fully read; the next strip complete in the other buffer
+        if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[4] += t - dt; dt = t; }
         buf ^= 1;
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) diag[((size_t)blockIdx.x * 8 + wave) * 5 + k] = dg[k];
+        }
     }
 }
 
@@ -233,25 +261,40 @@ size_t pack_frags(const float* hwio, float* dst)
     return total;
 }
 
+unsigned long long* g_wu_diag[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+int g_wu_diag_blocks[6] = {0, 0, 0, 0, 0, 0};
+
 template <class C>
-hipError_t launch(const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
+hipError_t launch(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
 {
     static int resident = 0;
+    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
     if (!resident) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_up_kernel<C>, C::THREADS, C::LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_up_kernel<C, false>, C::THREADS, C::LDS);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
+        if (diag) {
+            if ((e = hipMalloc(&g_wu_diag[layer], (size_t)resident * 40 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_wu_diag_blocks[layer] = resident;
+        }
     }
     const long total = (long)n_cells * C::NGRP;
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv_wino_up_kernel<C>, dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells);
+    if (diag)
+        hipLaunchKernelGGL((conv_wino_up_kernel<C, true>), dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+                           g_wu_diag[layer]);
+    else
+        hipLaunchKernelGGL((conv_wino_up_kernel<C, false>), dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+                           (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
@@ -265,9 +308,25 @@ size_t pack_wino_up_fragments(int layer, const float* hwio, float* dst)
 hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream)
 {
-    if (layer == 5) return launch<WUL6>(in, ufrag, ep, out, n_cells, stream);
-    if (layer == 4) return launch<WUL5>(in, ufrag, ep, out, n_cells, stream);
+    if (layer == 5) return launch<WUL6>(layer, in, ufrag, ep, out, n_cells, stream);
+    if (layer == 4) return launch<WUL5>(layer, in, ufrag, ep, out, n_cells, stream);
     return hipErrorInvalidValue;
 }
 
 }  // namespace cs
+
+// Diagnostic only (CS_WINO_DIAG=1): per-wave phase cycles of the LAST launch of `layer` (4 or 5), averaged over waves.
+extern "C" int cs_debug_wino_up_diag(int layer, double out5[5])
+{
+    using namespace cs;
+    if (layer < 4 || layer > 5 || !g_wu_diag[layer]) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const size_t n = (size_t)g_wu_diag_blocks[layer] * 40;
+    unsigned long long* h = new unsigned long long[n];
+    if (hipMemcpy(h, g_wu_diag[layer], n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { delete[] h; return -3; }
+    for (int k = 0; k < 5; ++k) out5[k] = 0.0;
+    for (size_t i = 0; i < n; ++i) out5[i % 5] += (double)h[i];
+    for (int k = 0; k < 5; ++k) out5[k] /= (double)(n / 5);
+    delete[] h;
+    return 0;
+}

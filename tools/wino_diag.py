@@ -32,3 +32,17 @@ for layer, groups in ((1, 16), (2, 4)):
           f"launch {ms:.3f} ms -> s_memtime rate {tot / (ms * 1e-3) / 1e9:.3f} GHz")
     for n_, a in zip(names, v):
         print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
+
+# the F(2x2,2x2) phase kernels of conv5 / conv6 (one 512-thread workgroup per CU)
+f = e.reconstruct(x, want_recon=False)
+prof = e.profile()
+names5 = ["load issue", "transform+MFMA", "epilogue+stores", "strip writes", "barrier"]
+for layer, groups in ((5, 4), (4, 1)):
+    out = (C.c_double * 5)()
+    rc = lib.cs_debug_wino_up_diag(layer, out)
+    v = list(out)
+    tot = sum(v)
+    items = N * groups / 256
+    print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608)")
+    for n_, a in zip(names5, v):
+        print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
