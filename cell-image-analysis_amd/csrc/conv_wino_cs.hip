@@ -265,6 +265,174 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
     }
 }
 
+// ---- conv2 with a ring of staged rows --------------------------------------------------------------
+// Consecutive 16-tile groups of a cell (one tile row = 2 conv rows each) share two of their four staged rows.
+// The strip double buffer above reloads all four; here a workgroup walks whole cells and keeps the staged rows
+// in an 8-slot ring (same 39 KB): each group loads only the two rows the next group adds (three + a zero row
+// when the next group starts a new cell), one 16-byte load per thread and row.  Halves conv2's reads (255 ->
+// ~130 KB per cell) and the load-issue / LDS-write cycles of the prefetch.  Sequence rows: q = 0..33 per cell,
+// q = 0 and q = 33 are the zero halo rows; running position P = cell_iter * 34 + q lives in slot P & 7; the
+// halo COLUMNS of every slot are zeroed once and never written again.
+constexpr int RG_SLOTS = 8;
+
+__global__ __launch_bounds__(256, 2) void conv2_wino_ring_kernel(const float* __restrict__ in, const float* __restrict__ ufrag,
+                                                                const float* __restrict__ ep, float* __restrict__ out, long n_cells)
+{
+    using C = WinoL2;
+    constexpr int ROWF = C::WP * C::PS;                              // floats per ring slot
+    constexpr int RING = RG_SLOTS * ROWF * 4;                        // bytes
+    static_assert(RING == 2 * C::STRIP && C::TR == 1 && C::W * C::C4 == 256, "ring geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const ring = (float*)smem;
+    float* const xch = (float*)(smem + RING);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    float B[C::NB];
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) B[s] = ufrag[((size_t)wc * C::NB + s) * 64 + lane];
+    const int ca = wc == 0 ? 0 : (wc == 2 ? 2 : 1);
+    const int cb = wc == 2 ? 1 : (wc == 3 ? 3 : 2);
+    const float sg = wc == 1 ? 1.0f : -1.0f;
+    const int pcol = (2 * li) * C::PS + 4 * kq;                      // tile li's first patch column, this lane's channel quad
+    const int fs = wc, co = fs * 16 + li;                            // NS == 4: wave w finishes slice w
+    float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+    asm volatile("" : "+v"(bias), "+v"(bns), "+v"(bnt));
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
+
+    // this thread's element of a staged row: pixel tid >> 3, channel quad tid & 7
+    const int spx = tid >> 3, sc4 = tid & 7;
+    const int soff = (spx + 1) * C::PS + sc4 * 4;                    // +1: halo column
+    const int goff = spx * C::CIN + sc4 * 4;
+    auto row_ptr = [&](long cell, int y) { return in + ((size_t)cell * C::H + y) * C::W * C::CIN + goff; };
+
+    const long my_cells = (n_cells - blockIdx.x + gridDim.x - 1) / gridDim.x;   // cells blockIdx, +grid, ...
+    if (my_cells <= 0) return;
+    for (int idx = tid; idx < RG_SLOTS * ROWF / 4; idx += 256) ((f32x4*)ring)[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    // first cell: q = 1..3 (rows 0..2) into slots 1..3; q = 0 stays zero
+#pragma unroll
+    for (int q = 1; q <= 3; ++q) *(f32x4*)(ring + q * ROWF + soff) = *(const f32x4*)row_ptr(blockIdx.x, q - 1);
+    __syncthreads();
+
+    // the first channel group's patch reads of a group are issued before barrier B of the previous group, so
+    // their latency hides behind the epilogue instead of heading the transform
+    f32x4 pa[4], pb[4];
+    auto patch_q0 = [&](long Pn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ro = (int)((Pn + i) & (RG_SLOTS - 1)) * ROWF;
+            pa[i] = *(const f32x4*)(ring + pcol + ca * C::PS + ro);
+            pb[i] = *(const f32x4*)(ring + pcol + cb * C::PS + ro);
+        }
+    };
+    patch_q0(0);
+    const long n_items = my_cells * C::NGRP;
+    for (long it = 0; it < n_items; ++it) {
+        const long ci = it / C::NGRP;
+        const int grp = (int)(it % C::NGRP);
+        const long cell = blockIdx.x + ci * gridDim.x;
+        const long P = ci * 34 + 2 * grp;                            // running position of the group's first row
+        const bool has_next = it + 1 < n_items;
+        const bool new_cell = grp == C::NGRP - 1;                    // the next group starts the next cell
+
+        // rows the next group adds: same cell q = 2 grp + 4, + 5 (y = 2 grp + 3, + 4; y = 32 is the zero row),
+        // or the next cell's q = 0..3 (zero row, y = 0..2)
+        f32x4 stg[3];
+        if (has_next) {
+            if (!new_cell) {
+                const int y = 2 * grp + 3;
+                stg[0] = *(const f32x4*)row_ptr(cell, y);
+                stg[1] = *(const f32x4*)row_ptr(cell, y + 1 < C::H ? y + 1 : y);     // clamped; zeroed at the write if y + 1 == H
+            } else {
+                const long nc = cell + gridDim.x;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) stg[j] = *(const f32x4*)row_ptr(nc, j);
+            }
+        }
+
+        int roff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) roff[i] = (int)((P + i) & (RG_SLOTS - 1)) * ROWF;
+        const float* da_p = ring + pcol + ca * C::PS;
+        const float* db_p = ring + pcol + cb * C::PS;
+        f32x4 V[C::NQ][4];
+#pragma unroll
+        for (int q = 0; q < C::NQ; ++q) {
+            f32x4 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (q == 0) {
+                    w[i] = pa[i] + sg * pb[i];
+                } else {
+                    const f32x4 da = *(const f32x4*)(da_p + roff[i] + 16 * q);
+                    const f32x4 db = *(const f32x4*)(db_p + roff[i] + 16 * q);
+                    w[i] = da + sg * db;
+                }
+            }
+            V[q][0] = w[0] - w[2]; V[q][1] = w[1] + w[2]; V[q][2] = w[2] - w[1]; V[q][3] = w[1] - w[3];
+        }
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][r][j], B[(r * C::NS + s) * C::KS + 4 * q + j], acc[r], 0, 0, 0);
+            f32x4 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+                s1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+            }
+            float* x = xch + ((size_t)((wc * C::NS + s) * 2) * 64 + lane) * 4;
+            *(f32x4*)x = s0;
+            *(f32x4*)(x + 64 * 4) = s1;
+        }
+        if (has_next) {
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!new_cell) {
+                const int y = 2 * grp + 3;
+                *(f32x4*)(ring + (int)((P + 4) & (RG_SLOTS - 1)) * ROWF + soff) = stg[0];
+                *(f32x4*)(ring + (int)((P + 5) & (RG_SLOTS - 1)) * ROWF + soff) = (y + 1 < C::H) ? stg[1] : zero;
+            } else {
+                *(f32x4*)(ring + (int)((P + 4) & (RG_SLOTS - 1)) * ROWF + soff) = zero;        // q = 0 of the next cell
+#pragma unroll
+                for (int j = 0; j < 3; ++j) *(f32x4*)(ring + (int)((P + 5 + j) & (RG_SLOTS - 1)) * ROWF + soff) = stg[j];
+            }
+        }
+        __syncthreads();   // s of all four columns in LDS; the next group's rows complete
+
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* x = xch + ((size_t)((c * C::NS + fs) * 2) * 64 + lane) * 4;
+            t0[c] = *(const f32x4*)x;
+            t1[c] = *(const f32x4*)(x + 64 * 4);
+        }
+        const f32x4 y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+        const f32x4 y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+        if (has_next) patch_q0(new_cell ? P + 4 : P + 2);            // the next group's first row
+        auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float a = y00[rr], b = y01[rr], c2 = y10[rr], d = y11[rr];
+            const float mx = fmaxf(fmaxf(a, b), fmaxf(c2, d)), mn = fminf(fminf(a, b), fminf(c2, d));
+            const float res = post(bns >= 0.0f ? mx : mn);
+            const int t = 4 * kq + rr;
+            out[(((size_t)cell * (C::H / 2) + grp) * (C::W / 2) + t) * C::COUT + co] = res;
+        }
+        __syncthreads();   // exchange area free again
+    }
+}
+
 template <class C>
 size_t pack_frags(const float* hwio, float* dst)
 {
@@ -336,6 +504,25 @@ size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst)
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream)
 {
+    static const bool no_ring = getenv("CS_WINO_NO_RING") != nullptr || getenv("CS_WINO_DIAG") != nullptr;
+    if (layer == 1 && !no_ring) {
+        static int resident = 0;
+        constexpr int lds = 2 * WinoL2::STRIP + WinoL2::XCH;
+        if (!resident) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv2_wino_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            int dev = 0, cus = 0, per_cu = 0;
+            if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv2_wino_ring_kernel, 256, lds)) != hipSuccess) return e;
+            if (per_cu < 1) per_cu = 1;
+            resident = cus * per_cu;
+        }
+        if (n_cells <= 0) return hipSuccess;
+        const unsigned grid = (unsigned)(n_cells < resident ? n_cells : resident);
+        hipLaunchKernelGGL(conv2_wino_ring_kernel, dim3(grid), dim3(256), lds, stream, in, ufrag, ep, out, (long)n_cells);
+        return hipGetLastError();
+    }
     if (layer == 1) return launch<WinoL2>(layer, in, ufrag, ep, out, n_cells, stream);
     if (layer == 2) return launch<WinoL3>(layer, in, ufrag, ep, out, n_cells, stream);
     return hipErrorInvalidValue;
