@@ -172,4 +172,18 @@ def test_training_class_mirror(tmp_path):
     assert 0.0 <= r["conservative_anomaly_rate"] <= 0.5
 
 
+def test_training_with_the_reference_augmentation(tmp_path):
+    """augment="reference": the generator of CAE_improved_modeltrain.py:246-254 on the GPU, input only (:287)."""
+    from cellscreen.training import ImprovedAnomalyDetectionTraining
+    cells = synth.blob_crops(22, 320)
+    t = ImprovedAnomalyDetectionTraining(str(tmp_path / "aug"), epochs=3, verbose=0, augment="reference")
+    _, _, history = t.train_autoencoder(cells)
+    h = history.history
+    assert len(h["loss"]) == 3 and np.isfinite(h["loss"]).all() and h["loss"][-1] < h["loss"][0]
+    assert callable(t.augment)                              # the hook was bound to the trainer's generator
+    t2 = ImprovedAnomalyDetectionTraining(str(tmp_path / "plain"), epochs=3, verbose=0)
+    _, _, h2 = t2.train_autoencoder(cells)
+    assert h2.history["loss"] != h["loss"]                  # the augmented run really saw different inputs
+
+
 import os  # noqa: E402
