@@ -90,6 +90,11 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
 hipError_t launch_recon_err(const float* recon, const float* x, int64_t n, int npix, float* errpart, hipStream_t stream);
 // training augmentation: affine bilinear resample (nearest fill) + flips, one image per workgroup
 hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s);
+// one launch for every operand pack of a training step: transposed = 0 forward fragments, 1 backward-data fragments,
+// 2 conv7's effective weights (cin/cout ignored)
+struct PackJob { const float* src; float* dst; int cin, cout, transposed, blocks; };
+struct PackTable { PackJob job[16]; int n; };
+hipError_t launch_pack_all(PackTable& tab, hipStream_t s);
 hipError_t launch_pack_frag(const float* hwio, int cin, int cout, int transposed, float* dst, hipStream_t s);
 hipError_t launch_pack_w7eff(const float* w7, float* weff, hipStream_t s);
 hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* beta, const float* mov_mean,

@@ -585,6 +585,42 @@ __global__ void pack_frag_kernel(const float* __restrict__ hwio, int cin, int co
     dst[i] = v;
 }
 
+// All operand packs of one training step in ONE launch (12 fragment packs + W_eff of conv7): after every Adam
+// update the MFMA B fragments of the six forward convs and of the six backward-data convs are rebuilt from the
+// HWIO parameters; as 13 launches of ~2.5 us that was 5 % of a batch-32 step.
+__global__ void pack_all_kernel(PackTable tab)
+{
+    int job = 0, b = blockIdx.x;
+    while (job < tab.n - 1 && b >= tab.job[job].blocks) { b -= tab.job[job].blocks; ++job; }
+    const PackJob J = tab.job[job];
+    const int i = b * blockDim.x + threadIdx.x;
+    if (J.transposed == 2) {                                  // conv7's effective weights
+        if (i >= 16 * 32) return;
+        const int ci = i & 31, e = i >> 5;
+        const int rx = e & 1, ry = (e >> 1) & 1, bb = (e >> 2) & 1, a = (e >> 3) & 1;
+        float sum = 0.0f;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+                if (((a + dy) >> 1) + 1 == a + ry && ((bb + dx) >> 1) + 1 == bb + rx) sum += J.src[((dy + 1) * 3 + (dx + 1)) * 32 + ci];
+        J.dst[i] = sum;
+        return;
+    }
+    const int cin = J.cin, cout = J.cout, transposed = J.transposed;
+    const int ecin = transposed ? cout : cin, ecout = transposed ? cin : cout;
+    const int kq_n = ecin / 16, nb = (ecin == 1) ? 3 : 9 * kq_n * 4;
+    const int total = (ecout / 16) * nb * 64;
+    if (i >= total) return;
+    const int lane = i & 63, s = (i >> 6) % nb, nsl = (i >> 6) / nb;
+    const int li = lane & 15, kq = lane >> 4, co = nsl * 16 + li;
+    int tap, ci;
+    bool valid = true;
+    if (ecin == 1) { tap = 4 * s + kq; ci = 0; valid = tap < 9; }
+    else { const int j = s & 3, q = (s >> 2) % kq_n; tap = (s >> 2) / kq_n; ci = 16 * q + 4 * kq + j; }
+    float v = 0.0f;
+    if (valid) v = transposed ? J.src[((size_t)(8 - tap) * cin + co) * cout + ci] : J.src[((size_t)tap * cin + ci) * cout + co];
+    J.dst[i] = v;
+}
+
 // W_eff[a][b][ry][rx][ci] of conv7_err_kernel from the HWIO (3,3,32,1) kernel in device memory.
 __global__ void pack_w7eff_kernel(const float* __restrict__ w7, float* __restrict__ weff)
 {
@@ -727,6 +763,24 @@ hipError_t launch_pack_frag(const float* hwio, int cin, int cout, int transposed
     const int nb = (ecin == 1) ? 3 : 9 * (ecin / 16) * 4;
     const int total = (ecout / 16) * nb * 64;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, hwio, cin, cout, transposed, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_all(PackTable& tab, hipStream_t s)
+{
+    int blocks = 0;
+    for (int k = 0; k < tab.n; ++k) {
+        PackJob& J = tab.job[k];
+        int total;
+        if (J.transposed == 2) total = 16 * 32;
+        else {
+            const int ecin = J.transposed ? J.cout : J.cin, ecout = J.transposed ? J.cin : J.cout;
+            total = (ecout / 16) * ((ecin == 1) ? 3 : 9 * (ecin / 16) * 4) * 64;
+        }
+        J.blocks = (total + 255) / 256;
+        blocks += J.blocks;
+    }
+    hipLaunchKernelGGL(pack_all_kernel, dim3(blocks), dim3(256), 0, s, tab);
     return hipGetLastError();
 }
 

@@ -44,11 +44,12 @@ static size_t r_floats(int l) { return (size_t)kConvGrid[l] * kConvGrid[l] * kRe
 static int repack(cs_trainer* t)
 {
     float* P = t->P.as<float>();
-    for (int l = 0; l < 6; ++l)
-        LCHK(launch_pack_frag(P + t->off_k[l], cin_of(l), kRefChannels[l], 0, t->wf[l].as<float>(), t->stream));
-    for (int l = 1; l < 7; ++l)
-        LCHK(launch_pack_frag(P + t->off_k[l], cin_of(l), kRefChannels[l], 1, t->wft[l].as<float>(), t->stream));
-    LCHK(launch_pack_w7eff(P + t->off_k[6], t->w7eff.as<float>(), t->stream));
+    PackTable tab;
+    tab.n = 0;
+    for (int l = 0; l < 6; ++l) tab.job[tab.n++] = PackJob{P + t->off_k[l], t->wf[l].as<float>(), cin_of(l), kRefChannels[l], 0, 0};
+    for (int l = 1; l < 7; ++l) tab.job[tab.n++] = PackJob{P + t->off_k[l], t->wft[l].as<float>(), cin_of(l), kRefChannels[l], 1, 0};
+    tab.job[tab.n++] = PackJob{P + t->off_k[6], t->w7eff.as<float>(), 32, 1, 2, 0};
+    LCHK(launch_pack_all(tab, t->stream));
     return CS_OK;
 }
 
