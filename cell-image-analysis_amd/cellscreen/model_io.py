@@ -188,3 +188,86 @@ def cae_from_npz(path: str, prefix: str = "") -> CAEWeights:
     return CAEWeights([g(f"conv{l}_kernel") for l in range(n_conv)], [g(f"conv{l}_bias") for l in range(n_conv)],
                       [g(f"bn{l}_gamma") for l in range(n_bn)], [g(f"bn{l}_beta") for l in range(n_bn)],
                       [g(f"bn{l}_mean") for l in range(n_bn)], [g(f"bn{l}_var") for l in range(n_bn)]).validate()
+
+
+# ---- `.keras` archives (best_autoencoder.keras, encoder.keras of improved_detection.py:28-29) --------------
+def _suffix_key(name: str):
+    """Keras names the groups of a layer container <snake_case class>[_<n>] in container order:
+    conv2d, conv2d_1, conv2d_2, ... -> sort key (0, 1, 2, ...)."""
+    head, _, tail = name.rpartition("_")
+    return int(tail) if head and tail.isdigit() else 0
+
+
+def cae_from_keras(path: str) -> CAEWeights:
+    """Reads a Keras-3 `.keras` archive (zip: config.json + model.weights.h5) -- or a bare weights .h5 -- of the
+    reference's autoencoder or encoder WITHOUT Keras or h5py (cellscreen/h5lite.py parses the HDF5 file).
+    Layers are identified by what they store, not by their path prefix: a group whose `vars` holds a 4-D "0" and a
+    1-D "1" is a Conv2D (kernel HWIO, bias); one with four 1-D arrays is a BatchNormalization (gamma, beta,
+    moving_mean, moving_variance); optimizer slots and everything else are ignored.  Order = the numeric suffix of
+    the group name (conv2d, conv2d_1, ...), which is the model's layer order.  Input size, pooling count and the BN
+    epsilon come from config.json when present (else 64x64, the layer grammar's n_enc, Keras's 1e-3).
+    The layout follows the published Keras 3 saving code; no Keras install exists here to cross-check a real file --
+    the fixture under tests/golden is written with the real HDF5 library in that layout."""
+    import json
+    import zipfile
+    from . import h5lite
+    cfg = None
+    if zipfile.is_zipfile(path):
+        with zipfile.ZipFile(path) as z:
+            names = z.namelist()
+            wname = next((n for n in names if n.endswith("model.weights.h5")), None)
+            if wname is None:
+                raise ValueError(f"{path}: no model.weights.h5 inside the archive (found {names})")
+            tree = h5lite.read(z.read(wname))
+            if "config.json" in names:
+                cfg = json.loads(z.read("config.json"))
+    else:
+        tree = h5lite.read(path)
+    layers: Dict[str, Dict[int, np.ndarray]] = {}
+    for key, arr in tree.items():
+        parts = key.split("/")
+        if len(parts) >= 3 and parts[-2] == "vars" and parts[-1].isdigit() and "optimizer" not in parts[:-2]:
+            layers.setdefault("/".join(parts[:-2]), {})[int(parts[-1])] = arr
+    convs, bns = [], []
+    for lpath, v in layers.items():
+        name = lpath.split("/")[-1]
+        if len(v) == 2 and v.get(0) is not None and v[0].ndim == 4 and v[1].ndim == 1:
+            convs.append((_suffix_key(name), name, v))
+        elif len(v) == 4 and all(v[i].ndim == 1 for i in range(4)):
+            bns.append((_suffix_key(name), name, v))
+    convs.sort(key=lambda t: t[0]); bns.sort(key=lambda t: t[0])
+    if not convs or len(bns) not in (len(convs), len(convs) - 1):
+        raise ValueError(f"{path}: found {len(convs)} Conv2D and {len(bns)} BatchNormalization variable groups; "
+                         "not the reference's conv/BN chain")
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    hw, n_pool, eps = spec.INPUT_HW, None, spec.BN_EPS
+    if cfg is not None:
+        try:
+            ls = cfg["config"]["layers"]
+            n_pool = sum(1 for l in ls if l.get("class_name") == "MaxPooling2D")
+            for l in ls:
+                c = l.get("config", {})
+                shp = c.get("batch_shape") or c.get("batch_input_shape")
+                if l.get("class_name") == "InputLayer" and shp and len(shp) == 4:
+                    hw = (int(shp[1]), int(shp[2]))
+                if l.get("class_name") == "BatchNormalization" and "epsilon" in c:
+                    eps = float(c["epsilon"])
+        except (KeyError, TypeError):
+            pass
+    encoder_only = len(bns) == len(convs)
+    n_enc = n_pool if n_pool else (len(convs) if encoder_only else (len(convs) - 1) // 2)
+    return CAEWeights([f32(v[0]) for _, _, v in convs], [f32(v[1]) for _, _, v in convs],
+                      [f32(v[0]) for _, _, v in bns], [f32(v[1]) for _, _, v in bns],
+                      [f32(v[2]) for _, _, v in bns], [f32(v[3]) for _, _, v in bns], hw, n_enc, eps).validate()
+
+
+def convert_reference_model_dir(model_dir: str, out_dir: Optional[str] = None) -> str:
+    """The six files load_trained_models reads (improved_detection.py:28-41) -> the native file set
+    (cae.bin, detector.bin, manifest.json) next to them (or in out_dir).  Needs scikit-learn for the pickles,
+    nothing for the `.keras` archives."""
+    ae = cae_from_keras(os.path.join(model_dir, "best_autoencoder.keras"))
+    enc = cae_from_keras(os.path.join(model_dir, "encoder.keras"))
+    det = detector_from_reference_pickles(model_dir)
+    out = out_dir or model_dir
+    save_model_dir(out, ae, enc, det)
+    return out
