@@ -40,7 +40,10 @@ struct WinoCfg {
     static constexpr int LDS = 2 * STRIP + XCH;
     static constexpr int NGRP = H / SR;                  // groups per cell
     static constexpr int C4 = CIN / 4, TOT = R * WP * C4;
-    static constexpr int NLD = (TOT + 255) / 256;        // per-thread 16-B loads per strip
+    // staging: a thread owns one 16-byte element of the strip's INTERIOR columns per staged row (the halo columns are
+    // zeroed once at kernel start and never rewritten): W * C4 = 256 elements per row for both layers, no divisions
+    static constexpr int NLD = R;                        // per-thread 16-B loads per strip (one per row)
+    static_assert(W * C4 == 256, "one interior element per thread and row");
     static constexpr bool QOUTER = NQ > NS;              // which of V / accumulators is kept whole
     static constexpr int FR = NS;                        // tile registers a wave finishes (4*NS units / 4 waves)
     static_assert(NB == 128 && LDS <= 80 * 1024 && TW * TR == 16 && (NS == 2 || NS == 4), "layer does not fit this design");
@@ -48,34 +51,24 @@ struct WinoCfg {
 using WinoL2 = WinoCfg<32, 32, 32, 64>;
 using WinoL3 = WinoCfg<16, 16, 64, 32>;
 
-// Strip staging.  The load is UNCONDITIONAL (halo / out-of-range lanes read a clamped in-range address)
-// and the zero padding is applied when the value is written to LDS: a load under a divergent branch
-// makes the compiler wait for it (vmcnt(0)) right where it is issued, which serialises the prefetch.
+// Strip staging.  The load is UNCONDITIONAL (rows outside the image read a clamped in-range row) and the zero
+// padding is applied when the value is written to LDS: a load under a divergent branch makes the compiler wait for
+// it (vmcnt(0)) right where it is issued, which serialises the prefetch.  fp32 MFMA and VALU instructions never
+// execute together on a SIMD (PMC: SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the index arithmetic is per-thread constants
+// (goff / loff) + one row test.
 template <class C>
-__device__ __forceinline__ bool wn_valid(int y0, int idx, int& sy, int& sx, int& c4)
+__device__ __forceinline__ f32x4 wn_load(const float* __restrict__ cellp, int y0, int r, int goff)
 {
-    const int pix = idx / C::C4;
-    c4 = idx % C::C4;
-    const int r = pix / C::WP, c = pix % C::WP;
-    sy = y0 - 1 + r;
-    sx = c - 1;
-    return idx < C::TOT && sy >= 0 && sy < C::H && sx >= 0 && sx < C::W;
+    int sy = y0 - 1 + r;
+    sy = sy < 0 ? 0 : (sy > C::H - 1 ? C::H - 1 : sy);
+    return *(const f32x4*)(cellp + sy * (C::W * C::CIN) + goff);
 }
 template <class C>
-__device__ __forceinline__ f32x4 wn_load(const float* __restrict__ in, long cell, int y0, int idx)
+__device__ __forceinline__ void wn_store(float* strip, int y0, int r, int loff, f32x4 v)
 {
-    const float* src = in + (size_t)cell * C::H * C::W * C::CIN;
-    int sy, sx, c4;
-    const bool ok = wn_valid<C>(y0, idx, sy, sx, c4);
-    const int off = ok ? (sy * C::W + sx) * C::CIN + c4 * 4 : 0;
-    return *(const f32x4*)(src + off);
-}
-template <class C>
-__device__ __forceinline__ void wn_store(float* strip, int y0, int idx, f32x4 v)
-{
-    int sy, sx, c4;
-    if (!wn_valid<C>(y0, idx, sy, sx, c4)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (idx < C::TOT) *(f32x4*)(strip + (idx / C::C4) * C::PS + c4 * 4) = v;
+    const int sy = y0 - 1 + r;
+    if (sy < 0 || sy >= C::H) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    *(f32x4*)(strip + r * (C::WP * C::PS) + loff) = v;
 }
 
 // DIAG: diagnostic build that stamps s_memtime at the phase boundaries of every group and sums the
@@ -129,9 +122,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
     const long total = n_cells * C::NGRP;
     const long first = blockIdx.x;
     if (first >= total) return;
-#pragma unroll 4
-    for (int idx = tid; idx < C::TOT; idx += 256)
-        wn_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, idx, wn_load<C>(in, first / C::NGRP, (int)(first % C::NGRP) * C::SR, idx));
+    const int spx = tid / C::C4, sc4 = tid % C::C4;                 // this thread's interior element of a staged row
+    const int goff = spx * C::CIN + sc4 * 4, loff = (spx + 1) * C::PS + sc4 * 4;
+    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::H * C::W * C::CIN; };
+    for (int i = tid; i < 2 * C::STRIP / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C::R; ++r)
+        wn_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, r, loff, wn_load<C>(cell_ptr(first / C::NGRP), (int)(first % C::NGRP) * C::SR, r, goff));
     __syncthreads();
 
     f32x4 stg[C::NLD];
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
         if constexpr (DIAG) dt = wcs_stamp();
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < C::NLD; ++j) stg[j] = wn_load<C>(in, nitem / C::NGRP, (int)(nitem % C::NGRP) * C::SR, tid + 256 * j);
+            for (int j = 0; j < C::NLD; ++j) stg[j] = wn_load<C>(cell_ptr(nitem / C::NGRP), (int)(nitem % C::NGRP) * C::SR, j, goff);
         }
         if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[5] += t - dt; }
         const float* da_p = strip + poff + ca * C::PS;
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
         if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[0] += t - dt; dt = t; }
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < C::NLD; ++j) wn_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, tid + 256 * j, stg[j]);
+            for (int j = 0; j < C::NLD; ++j) wn_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, j, loff, stg[j]);
         }
         if constexpr (DIAG) { const unsigned long long t = wcs_stamp(); dg[1] += t - dt; dt = t; }
         __syncthreads();   // s of all four columns in LDS; this strip fully read; next strip complete

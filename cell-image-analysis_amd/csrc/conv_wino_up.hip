@@ -46,37 +46,34 @@ struct WUCfg {
     static constexpr int NB = 9 * KS * NSW;                    // B registers (144 for both layers)
     static constexpr int C4 = CIN / 4, TOT = R * WP * C4;
     static constexpr int THREADS = 512;
-    static constexpr int NLD = (TOT + THREADS - 1) / THREADS;
+    // staging: a thread owns one 16-byte element of the strip's INTERIOR columns per pass (the halo columns are zeroed
+    // once at kernel start and never rewritten), rows RPP at a time -- no divisions, the only run-time test is the row
+    static constexpr int EPR = WS * C4;                        // interior elements per staged row (256 | 64)
+    static constexpr int RPP = THREADS / EPR;                  // rows per pass (2 | 8)
+    static constexpr int NLD = (R + RPP - 1) / RPP;            // passes = loads per thread per strip (3 | 2)
+    static_assert(THREADS % EPR == 0 && (EPR & (EPR - 1)) == 0 && (C4 & (C4 - 1)) == 0, "row-wise staging");
     static_assert(NB == 144 && LDS <= 160 * 1024 && HS % SR == 0 && (NSW == 1 || NSW == 2), "layer does not fit this design");
 };
 using WUL6 = WUCfg<16, 16, 64, 32>;    // conv6: a5 16x16x64 -> a6 32x32x32
 using WUL5 = WUCfg<8, 8, 32, 64>;      // conv5: a4 8x8x32  -> a5 16x16x64
 
+// fp32 MFMA and VALU instructions never execute together on a SIMD (PMC: SQ_VALU_MFMA_COEXEC_CYCLES = 0; a
+// kernel's time is 32 x MFMAs + 4 x VALU instructions per SIMD), so the index arithmetic of the staging is on the
+// critical path: it is reduced to per-thread constants + one row test.
 template <class C>
-__device__ __forceinline__ bool wu_valid(int y0, int idx, int& sy, int& sx, int& c4)
+__device__ __forceinline__ f32x4 wu_load(const float* __restrict__ cellp, int y0, int j, int rsub, int goff)
 {
-    const int pix = idx / C::C4;
-    c4 = idx % C::C4;
-    const int r = pix / C::WP, c = pix % C::WP;
-    sy = y0 - 1 + r;
-    sx = c - 1;
-    return idx < C::TOT && sy >= 0 && sy < C::HS && sx >= 0 && sx < C::WS;
-}
-// unconditional load from a clamped address; the zero padding is applied at the LDS write
-template <class C>
-__device__ __forceinline__ f32x4 wu_load(const float* __restrict__ in, long cell, int y0, int idx)
-{
-    const float* src = in + (size_t)cell * C::HS * C::WS * C::CIN;
-    int sy, sx, c4;
-    const bool ok = wu_valid<C>(y0, idx, sy, sx, c4);
-    return *(const f32x4*)(src + (ok ? (sy * C::WS + sx) * C::CIN + c4 * 4 : 0));
+    int sy = y0 - 1 + rsub + C::RPP * j;
+    sy = sy < 0 ? 0 : (sy > C::HS - 1 ? C::HS - 1 : sy);          // clamped: the load is unconditional
+    return *(const f32x4*)(cellp + sy * (C::WS * C::CIN) + goff);
 }
 template <class C>
-__device__ __forceinline__ void wu_store(float* strip, int y0, int idx, f32x4 v)
+__device__ __forceinline__ void wu_store(float* strip, int y0, int j, int rsub, int loff, f32x4 v)
 {
-    int sy, sx, c4;
-    if (!wu_valid<C>(y0, idx, sy, sx, c4)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (idx < C::TOT) *(f32x4*)(strip + (idx / C::C4) * C::PS + c4 * 4) = v;
+    const int r = rsub + C::RPP * j;
+    const int sy = y0 - 1 + r;
+    if (sy < 0 || sy >= C::HS) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // halo rows of the image
+    if (C::R % C::RPP == 0 || r < C::R) *(f32x4*)(strip + r * (C::WP * C::PS) + loff) = v;
 }
 
 // DIAG: diagnostic build, s_memtime stamps summed per wave: [0] next-strip load issue, [1] transforms + MFMAs,
@@ -124,11 +121,18 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
     const long total = n_cells * C::NGRP;
     const long first = blockIdx.x;
     if (first >= total) return;
+    // staging constants of this thread: interior element e of a row, row rsub of a pass
+    const int se = tid & (C::EPR - 1), rsub = tid / C::EPR;
+    const int spx = se / C::C4, sc4 = se & (C::C4 - 1);
+    const int goff = spx * C::CIN + sc4 * 4;                       // inside a stored row
+    const int loff = (spx + 1) * C::PS + sc4 * 4;                  // inside a strip row (+1: halo column)
+    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::HS * C::WS * C::CIN; };
+    for (int i = tid; i < 2 * C::STRIP / 16; i += C::THREADS) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < C::NLD; ++j) {
-        const int idx = tid + C::THREADS * j;
-        wu_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, idx, wu_load<C>(in, first / C::NGRP, (int)(first % C::NGRP) * C::SR, idx));
-    }
+    for (int j = 0; j < C::NLD; ++j)
+        wu_store<C>((float*)smem, (int)(first % C::NGRP) * C::SR, j, rsub, loff,
+                    wu_load<C>(cell_ptr(first / C::NGRP), (int)(first % C::NGRP) * C::SR, j, rsub, goff));
     __syncthreads();
 
     int buf = 0;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
         f32x4 stg[C::NLD];
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(in, nitem / C::NGRP, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j);
+            for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(cell_ptr(nitem / C::NGRP), (int)(nitem % C::NGRP) * C::SR, j, rsub, goff);
         }
         if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[0] += t - dt; dt = t; }
 
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
         }
         if (has_next) {
 #pragma unroll
-            for (int j = 0; j < C::NLD; ++j) wu_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, tid + C::THREADS * j, stg[j]);
+            for (int j = 0; j < C::NLD; ++j) wu_store<C>(nstrip, (int)(nitem % C::NGRP) * C::SR, j, rsub, loff, stg[j]);
         }
         if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
         __syncthreads();   // this strip fully read; the next strip complete in the other buffer
