@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
     asm volatile("" : "+v"(bias), "+v"(bns), "+v"(bnt));
+    const bool all_up = __all(bns >= 0.0f) != 0;          // wave-uniform: pooled epilogue can take the max-only path
 
     // conv1: per-lane tap of each of the 3 K steps (k = 4 s + kq; k >= 9 is zero padding)
     int toff[3];
@@ -345,13 +346,19 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
 
             f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (C::CIN == 1) {
-                const int b0 = (py0 * C::WP + px0) * 4, b1 = (py1 * C::WP + px1) * 4;
+                // fp32 MFMA and VALU instructions do not overlap, and this layer has only 6 MFMAs
+                // per tile pair, so every VALU instruction here is on the critical path:
+                //  - the second tile of the pair sits a compile-time distance from the first (the row below when
+                //    pooling, the next 16 pixels otherwise), so its reads share the address register (ds_read offset);
+                //  - the lanes of the padded taps (k = 9..11) are not masked: their B values are zero, and what they read
+                //    (tap 0 of the same pixel) is finite whenever the true taps are, so 0 * a contributes exactly 0.
+                const int b0 = (py0 * C::WP + px0) * 4;
+                constexpr int D01 = C::POOL ? C::WP * 4 : 16 * 4;
+                static_assert(C::POOL || C::TPR % 2 == 0, "pair = two tiles of one row");
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    float a0 = *(const float*)(strip + b0 + toff[s]);
-                    float a1 = *(const float*)(strip + b1 + toff[s]);
-                    a0 = tval[s] ? a0 : 0.0f;
-                    a1 = tval[s] ? a1 : 0.0f;
+                    const float a0 = *(const float*)(strip + b0 + toff[s]);
+                    const float a1 = *(const float*)(strip + b0 + toff[s] + D01);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
                 }
@@ -411,13 +418,21 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                     // scale is >= 0, non-increasing where it is negative), so the max over the window of the
                     // mapped values is the map of the window's max (resp. min) of the raw sums -- the same bits
                     // for a third of the epilogue's VALU work
-                    const bool up = bns >= 0.0f;
-                    auto ext = [&](float a, float b, float c, float d) {
-                        const float mx = fmaxf(fmaxf(a, b), fmaxf(c, d)), mn = fminf(fminf(a, b), fminf(c, d));
-                        return up ? mx : mn;
-                    };
-                    o[0] = post(ext(acc0[0], acc0[1], acc1[0], acc1[1]));
-                    o[C::COUT] = post(ext(acc0[2], acc0[3], acc1[2], acc1[3]));
+                    // raw v_max / v_min (fmaxf would first canonicalise each operand with a v_max x, x)
+                    auto vmax = [](float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+                    auto vmin = [](float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+                    if (all_up) {   // every channel of this wave has a non-negative BN scale (wave-uniform, the usual case)
+                        o[0] = post(vmax(vmax(acc0[0], acc0[1]), vmax(acc1[0], acc1[1])));
+                        o[C::COUT] = post(vmax(vmax(acc0[2], acc0[3]), vmax(acc1[2], acc1[3])));
+                    } else {
+                        const bool up = bns >= 0.0f;
+                        auto ext = [&](float a, float b, float c, float d) {
+                            const float mx = vmax(vmax(a, b), vmax(c, d)), mn = vmin(vmin(a, b), vmin(c, d));
+                            return up ? mx : mn;
+                        };
+                        o[0] = post(ext(acc0[0], acc0[1], acc1[0], acc1[1]));
+                        o[C::COUT] = post(ext(acc0[2], acc0[3], acc1[2], acc1[3]));
+                    }
                 }
             } else {
 #pragma unroll
