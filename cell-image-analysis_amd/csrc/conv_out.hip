@@ -37,26 +37,29 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
     // The kernel is HBM-bound (it streams a6 once, 172 KB/cell with the row halo), so the strip of
     // item i+1 is loaded into registers before the arithmetic of item i and written to LDS after
     // it: loads stay in flight the whole time instead of only between items.
-    constexpr int C4 = C7_CIN / 4;
-    constexpr int TOT = C7_R * C7_WP * C4;
-    constexpr int NLD = (TOT + 255) / 256;
+    // Staging: a thread owns one interior 16-byte element (pixel tid >> 3, channel quad tid & 7) of every staged row
+    // -- 32 x 8 = 256 per row -- with constant offsets; the halo columns are zeroed once and never rewritten, rows
+    // outside the image are loaded from a clamped row and zeroed at the LDS write.  (VALU instructions are on this
+    // kernel's critical path: the div/mod index arithmetic of an element-wise mapping was a quarter of them.)
+    static_assert(C7_WS * (C7_CIN / 4) == 256, "one interior element per thread and row");
+    constexpr int NLD = C7_R;
+    const int goff = (tid >> 3) * C7_CIN + (tid & 7) * 4;
+    const int loff = (((tid >> 3) + 1) * C7_PS + (tid & 7) * 4) * 4;      // bytes inside a strip row
     f32x4 stg[NLD];
     auto issue = [&](long item) {
         const long cell = item / C7_NSTRIP;
         const int y0 = (int)(item % C7_NSTRIP) * C7_SR;
-        const float* src = a6 + (size_t)cell * C7_HS * C7_WS * C7_CIN;
+        const float* src = a6 + (size_t)cell * C7_HS * C7_WS * C7_CIN + goff;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + 256 * k;
-            const int pix = idx / C4, c4 = idx % C4;
-            const int r = pix / C7_WP, c = pix % C7_WP;
-            const int sy = y0 - 1 + r, sx = c - 1;
-            stg[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (idx < TOT && sy >= 0 && sy < C7_HS && sx >= 0 && sx < C7_WS)
-                stg[k] = *(const f32x4*)(src + ((size_t)sy * C7_WS + sx) * C7_CIN + c4 * 4);
+            int sy = y0 - 1 + k;
+            sy = sy < 0 ? 0 : (sy > C7_HS - 1 ? C7_HS - 1 : sy);
+            stg[k] = *(const f32x4*)(src + sy * (C7_WS * C7_CIN));
         }
     };
+    for (int i = tid; i < C7_LDS / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if ((long)blockIdx.x < total) issue(blockIdx.x);
+    __syncthreads();
     for (long item = blockIdx.x; item < total; item += gridDim.x) {
         const long cell = item / C7_NSTRIP;
         const int strip = (int)(item % C7_NSTRIP);
@@ -64,11 +67,10 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
 
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < TOT) {
-                const int pix = idx / C4, c4 = idx % C4;
-                *(f32x4*)(smem + (pix * C7_PS + c4 * 4) * 4) = stg[k];
-            }
+            const int sy = y0 - 1 + k;
+            f32x4 v = stg[k];
+            if (sy < 0 || sy >= C7_HS) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *(f32x4*)(smem + k * (C7_WP * C7_PS * 4) + loff) = v;
         }
         __syncthreads();
         if (item + gridDim.x < total) issue(item + gridDim.x);
