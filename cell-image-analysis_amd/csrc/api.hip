@@ -742,6 +742,12 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
         if (!user) return nullptr;
         return host_out ? (decltype(user))tmp.p + off : user + off;
     };
+    // an error inside the pipeline must not return while a copy from the caller's host buffer is still in flight
+    auto drain = [&](int code) {
+        (void)hipStreamSynchronize(m->copy_stream);
+        (void)hipStreamSynchronize(m->stream);
+        return code;
+    };
     int64_t i = 0;
     for (int64_t off = 0; off < n; off += ch, ++i) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
@@ -751,17 +757,17 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
             HIPCHK(hipStreamWaitEvent(m->stream, m->ev_in[b], 0));
             x = stage[b]->as<float>();
         }
-        if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, nullptr))) return rc;
+        if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, nullptr))) return drain(rc);
         const float* feat = m->act[m->arch.n_enc - 1].as<float>();
         if (!m->shared_encoder) {
             // encoder.keras differs from the autoencoder's encoder half: second encoder pass
             // (improved_detection.py:130), after the decoder has consumed the first pass's features.
-            if ((rc = run_convs(m, m->enc, x, nc, 0, m->arch.n_enc - 1, nullptr))) return rc;
+            if ((rc = run_convs(m, m->enc, x, nc, 0, m->arch.n_enc - 1, nullptr))) return drain(rc);
             feat = m->act[m->arch.n_enc - 1].as<float>();
         }
         if ((rc = run_tail(m, feat, nc, dst(mse, m->o_mse, off), dst(mae, m->o_mae, off), dst(cons_score, m->o_sc[0], off),
                            dst(mod_score, m->o_sc[1], off), dst(cons_pred, m->o_pr[0], off), dst(mod_pred, m->o_pr[1], off), true)))
-            return rc;
+            return drain(rc);
         if (host_in) {
             HIPCHK(hipEventRecord(m->ev_used[b], m->stream));
             const int64_t noff = off + ch;
