@@ -250,3 +250,14 @@ def test_full_size_properties(engine, weights, det):
     assert np.abs(r1["mod_score"].cpu().numpy()[idx] - ref["mod_score"]).max() <= tol
     rate = float((r1["cons_pred"] == -1).float().mean())
     assert 0.0 <= rate <= 1.0
+
+
+def test_plain_c_program_screens_through_the_abi(tmp_path, weights, det):
+    """examples/screen_demo.c: gcc-built, no Python in the process -- loads the native model dir and screens."""
+    import subprocess
+    from test_host_logic import _build_c_demo
+    d = str(tmp_path / "model")
+    model_io.save_model_dir(d, weights, None, det)
+    r = subprocess.run([_build_c_demo(), d, "300"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "reference-graph kernels" in r.stdout and "total_cells 300" in r.stdout

@@ -196,3 +196,27 @@ def test_extractor_errors_are_swallowed_like_the_reference(tmp_path):
         raise RuntimeError("bad tiff")
     s = _screener(tmp_path, extractor=boom)
     assert s.extract_quality_cells("whatever.tif") == ([], [])                    # :113-115
+
+
+def _build_c_demo():
+    import subprocess
+    exe = os.path.join(H.ROOT, "examples", "screen_demo")
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(H.ROOT, "include"), os.path.join(H.ROOT, "examples", "screen_demo.c"),
+           "-o", exe, "-L" + os.path.join(H.ROOT, "cell-image-analysis_amd"), "-lcellscreen",
+           "-Wl,-rpath," + os.path.join(H.ROOT, "cell-image-analysis_amd"), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_abi_is_usable_from_plain_c():
+    """include/cellscreen.h compiles as C and links against libcellscreen.so with gcc alone; without a GPU the
+    program stops at the no-device check (no CPU path)."""
+    import subprocess
+    L.load_library()                                   # the .so must exist
+    exe = _build_c_demo()
+    r = subprocess.run([exe, "/nonexistent", "4"], capture_output=True, text=True)
+    if L.load_library().cs_device_count() <= 0:
+        assert r.returncode == 3 and "no CPU path" in r.stderr
+    else:
+        assert r.returncode == 1 and "cs_model_load failed" in r.stderr
