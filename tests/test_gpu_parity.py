@@ -261,3 +261,33 @@ def test_plain_c_program_screens_through_the_abi(tmp_path, weights, det):
     r = subprocess.run([_build_c_demo(), d, "300"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "reference-graph kernels" in r.stdout and "total_cells 300" in r.stdout
+
+
+def test_scaler_is_bit_exact_through_one_hot_pca(weights, det):
+    """The scaler inside scaler_pca_kernel avoids the fp64 division (reciprocal multiply + a tie test that falls
+    back to the division); with one-hot PCA rows and zero mean projection the kernel's output IS the scaled feature,
+    so it can be compared bit-for-bit with numpy's float32((x - center) / float64 scale) on two million values."""
+    import copy
+    rng = np.random.default_rng(123)
+    F, C = 2048, 100
+    d = copy.deepcopy(det)
+    d.scaler_center = rng.normal(0.3, 0.2, F).astype(np.float32)
+    d.scaler_scale = np.exp(rng.normal(0.0, 2.0, F)).astype(np.float64) * (1.0 + 2.0 ** -30)   # awkward divisors
+    d.scaler_scale[:8] = [1.0, 3.0, 0.1, 7.0, 1e-3, 1e3, 1.0 / 3.0, 2.0 ** -20]
+    comps = np.zeros((C, F), np.float32)
+    cols = rng.choice(F, C, replace=False)
+    cols[:8] = np.arange(8)
+    comps[np.arange(C), cols] = 1.0
+    d.pca_components = comps
+    d.pca_mean = np.zeros(F, np.float32)
+    d.pca_mean_proj = np.zeros(C, np.float32)
+    e = Engine.from_weights(weights, None, d)
+    try:
+        x = rng.normal(0.3, 1.0, (20000, F)).astype(np.float32)
+        x[:50, :8] = d.scaler_center[:8]                       # exact zeros after centring
+        got = e.scaler_pca(x)
+    finally:
+        e.close()
+    t = (x[:, cols] - d.scaler_center[cols]).astype(np.float32)
+    want = (t.astype(np.float64) / d.scaler_scale[cols]).astype(np.float32)
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} scaled values differ"
