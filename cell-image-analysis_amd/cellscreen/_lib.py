@@ -82,6 +82,14 @@ SIGNATURES = {
     "cs_preproc_free": (None, [_P]),
     "cs_preprocess": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _L, C.c_double, _P, _P, _I]),
     "cs_preproc_last_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "cs_fit_create": (_I, [_I, C.POINTER(_P)]),
+    "cs_fit_free": (None, [_P]),
+    "cs_fit_scaler": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P]),
+    "cs_fit_pca_moments": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P, _P, _P]),
+    "cs_fit_project": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P, _P, _P, C.c_int32, _P]),
+    "cs_fit_ocsvm": (_I, [_P, _P, _L, C.c_int32, C.c_double, C.c_double, C.c_double, _L, _P, C.POINTER(C.c_double),
+                          C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_int32)]),
+    "cs_fit_last_ms": (_I, [_P, C.POINTER(C.c_double)]),
     "cs_synth_crops": (_I, [_P, C.c_uint64, _L, _L, C.c_int32, _P]),
     "cs_profile_enable": (_I, [_P, _I]),
     "cs_profile_reset": (_I, [_P]),

@@ -224,6 +224,38 @@ int cs_preprocess(cs_preproc *p, const void *pixels, int pixel_type, int64_t n_p
  * of the last cs_preprocess call. */
 int cs_preproc_last_timing(const cs_preproc *p, double *kernel_ms, int64_t *pixels);
 
+/* ---- detector fitting (create_anomaly_detector, CAE_improved_modeltrain.py:394-446) -------- */
+/* The fit of what cs_screen's tail evaluates, for the training set's encoder features
+ * (cs_encode output, [n][n_features] fp32, host or device).  Own handle, own stream.
+ *   cs_fit_scaler       RobustScaler().fit (:408-409): center_ = per-feature median (float32), scale_ = 75th - 25th
+ *                       percentile (float64, numpy's linear interpolation; spreads below 10 eps become 1).  Exact
+ *                       (radix select of the order statistics + numpy's arithmetic on them).  NaNs: CS_ERR_UNSUPPORTED.
+ *   cs_fit_pca_moments  what PCA(...).fit (:412-414) needs from the data: mean_ (float32, numpy's row-after-row sum)
+ *                       of the scaled features and the fp64 scatter matrix Xc^T Xc of the centred scaled features
+ *                       ([F][F], host).  The principal axes are the leading eigenvectors of scatter / (n - 1); the
+ *                       F x F eigenproblem is the host's (cellscreen/detector_fit.py uses LAPACK through numpy).
+ *                       n_features must be a multiple of 128, at most 8192.
+ *   cs_fit_project      scaler.transform + pca.transform of the training features with freshly fitted parameters
+ *                       (the kernel cs_screen uses), out [n][n_components] fp32 on the host.
+ *   cs_fit_ocsvm        OneClassSVM(kernel='rbf', nu).fit (:420-427): libsvm's SMO (second-order working-set selection,
+ *                       Qfloat kernel rows, eps stopping rule) with every iteration on the device.  x: [n][n_components]
+ *                       float64 host (what sklearn hands libsvm), gamma as resolved by sklearn ('scale':
+ *                       1 / (n_components * x.var())), eps = tol (sklearn default 1e-3), max_iter < 0 = unbounded.
+ *                       alpha: [n] dual variables (support vectors are the points with alpha > 0; dual_coef_ = alpha),
+ *                       rho = -intercept_ = offset_.  status: 0 converged, 1 stopped at max_iter. */
+typedef struct cs_fit cs_fit;
+int cs_fit_create(int device_id, cs_fit **out);
+void cs_fit_free(cs_fit *f);
+int cs_fit_scaler(cs_fit *f, const float *features, int64_t n, int32_t n_features, int kind, float *center, double *scale);
+int cs_fit_pca_moments(cs_fit *f, const float *features, int64_t n, int32_t n_features, int kind, const float *center,
+                       const double *scale, float *mean, double *scatter);
+int cs_fit_project(cs_fit *f, const float *features, int64_t n, int32_t n_features, int kind, const float *center,
+                   const double *scale, const float *components, const float *mean_proj, int32_t n_components, float *out);
+int cs_fit_ocsvm(cs_fit *f, const double *x, int64_t n, int32_t n_components, double gamma, double nu, double eps,
+                 int64_t max_iter, double *alpha, double *rho, double *obj, int64_t *n_iter, int32_t *status);
+/* Device time (HIP events on the handle's stream) of the last cs_fit_* call, transfers of results included. */
+int cs_fit_last_ms(const cs_fit *f, double *device_ms);
+
 /* ---- measurement ---------------------------------------------------------------- */
 /* When enabled, every kernel launch of this handle is bracketed by HIP events on the
  * handle's stream; totals are per kernel family.  Adds a stream sync per call. */
