@@ -18,7 +18,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 
 from . import model_io, spec, synth
-from .detector_fit import fit_detector
+from .detector_fit import fit_detector, fit_detector_device
 from .engine import Engine
 from .spec import CAEWeights
 from .trainer import Trainer
@@ -33,7 +33,8 @@ class History:
 
 class ImprovedAnomalyDetectionTraining:
     def __init__(self, output_dir: str, device_id: int = 0, seed: int = 42, epochs: int = spec.EPOCHS,
-                 batch_size: int = spec.BATCH_SIZE, augment: Optional[Callable] = None, verbose: int = 1):
+                 batch_size: int = spec.BATCH_SIZE, augment: Optional[Callable] = None, verbose: int = 1,
+                 detector_fit: str = "device"):
         self.output_dir = output_dir                       # CAE_improved_modeltrain.py:26-27
         os.makedirs(output_dir, exist_ok=True)
         self.device_id = device_id
@@ -41,6 +42,9 @@ class ImprovedAnomalyDetectionTraining:
         self.epochs, self.batch_size = epochs, batch_size
         self.augment = augment
         self.verbose = verbose
+        if detector_fit not in ("device", "sklearn"):
+            raise ValueError("detector_fit must be 'device' (csrc/fit.hip) or 'sklearn' (the reference's library on the host)")
+        self.detector_fit = detector_fit
 
     # ---- model -------------------------------------------------------------------------
     def create_improved_autoencoder(self, input_shape=(64, 64, 1)) -> CAEWeights:
@@ -136,8 +140,9 @@ class ImprovedAnomalyDetectionTraining:
 
     def create_anomaly_detector(self, encoder: CAEWeights, cell_images, autoencoder: Optional[CAEWeights] = None,
                                 best_autoencoder: Optional[CAEWeights] = None):
-        """:394-446.  encoder.predict on the GPU, the sklearn fit on the host (the reference's own
-        library), the four pickles AND a native model_dir at output_dir that
+        """:394-446.  encoder.predict and the scaler / PCA / one-class-SVM fit on the GPU
+        (detector_fit="device", csrc/fit.hip; "sklearn" runs the reference's own library on the
+        host instead), the four pickles AND a native model_dir at output_dir that
         ProductionMutantScreening(output_dir) loads: autoencoder weights = best_autoencoder
         (what improved_detection.py:28 loads), encoder weights = `encoder` (:29)."""
         print("=== Creating Anomaly Detector ===")
@@ -148,7 +153,10 @@ class ImprovedAnomalyDetectionTraining:
         features_flat = e.encode(np.asarray(cell_images, dtype=np.float32), which=1)    # :401-402
         e.close()
         print(f"Flattened features shape: {features_flat.shape}")
-        params, objs = fit_detector(features_flat, output_dir=self.output_dir)           # :408-444
+        if self.detector_fit == "device":                                               # :408-444
+            params, objs = fit_detector_device(features_flat, output_dir=self.output_dir, device_id=self.device_id)
+        else:
+            params, objs = fit_detector(features_flat, output_dir=self.output_dir)
         print(f"PCA reduced to {params.n_components} components")
         print("\nBaseline anomaly rates:")                                              # :430-434
         for name, det in objs["detectors"].items():
