@@ -21,6 +21,9 @@
  *        stage-level taps used by the parity tests (oracle inputs to each stage)
  *   cs_preprocess
  *        equalize_adapthist + resize of each crop   improved_detection.py:98-99, CAE...:92-93
+ *   cs_fit_scaler / cs_fit_pca_moments / cs_fit_project / cs_fit_ocsvm
+ *        RobustScaler / PCA / OneClassSVM fits of create_anomaly_detector
+ *                                                 CAE_improved_modeltrain.py:408-427
  *   cs_synth_crops
  *        synthetic U[0,1) crops (no reference counterpart; benchmark/test input)
  *   cs_train_create / cs_train_step / cs_train_eval / cs_train_export

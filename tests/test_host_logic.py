@@ -220,3 +220,47 @@ def test_c_abi_is_usable_from_plain_c():
         assert r.returncode == 3 and "no CPU path" in r.stderr
     else:
         assert r.returncode == 1 and "cs_model_load failed" in r.stderr
+
+
+def test_sklearn_objects_rebuilt_from_fit_results_answer_like_fitted_ones(tmp_path):
+    """The host half of the device detector fit (cellscreen/detector_fit.py): estimators rebuilt from plain arrays
+    must behave like scikit-learn-fitted ones, since the reference unpickles and calls them
+    (improved_detection.py:32-41, 134-142)."""
+    import pickle
+    from sklearn.decomposition import PCA
+    from sklearn.preprocessing import RobustScaler
+    from sklearn.svm import OneClassSVM
+    from cellscreen import detector_fit as df
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(300, 6)) @ rng.normal(size=(6, 64)) + 0.1 * rng.normal(size=(300, 64))).astype(np.float32)
+    sc = RobustScaler().fit(x)
+    sc2 = pickle.loads(pickle.dumps(df._sklearn_scaler(sc.center_, sc.scale_)))
+    xs = sc.transform(x)
+    assert np.array_equal(sc2.transform(x), xs)
+    # principal axes from the scatter matrix == PCA(svd_solver='full'), order and signs included
+    full = PCA(n_components=6, svd_solver="full").fit(xs)
+    xc = (xs - xs.mean(axis=0)).astype(np.float64)
+    comps, ev, total = df.principal_axes(xc.T @ xc, len(x), 6)
+    assert np.abs(comps - full.components_).max() < 1e-4
+    assert np.allclose(ev, full.explained_variance_, rtol=1e-4)
+    p2 = pickle.loads(pickle.dumps(df._sklearn_pca(comps.astype(np.float32), xs.mean(axis=0), ev, total, len(x))))
+    assert np.abs(p2.transform(xs) - full.transform(xs)).max() < 1e-3
+    assert np.allclose(p2.explained_variance_ratio_, full.explained_variance_ratio_, rtol=1e-3)
+    # a OneClassSVM carrying somebody else's solve
+    red = full.transform(xs).astype(np.float64)
+    det = OneClassSVM(kernel="rbf", gamma="scale", nu=0.1).fit(red)
+    alpha = np.zeros(len(red))
+    alpha[det.support_] = det.dual_coef_.ravel()
+    d2 = pickle.loads(pickle.dumps(df.sklearn_ocsvm(red, alpha, -det.intercept_[0], det._gamma, 0.1, det.n_iter_)))
+    y = rng.normal(size=(40, 6)) * 3
+    assert np.array_equal(d2.decision_function(y), det.decision_function(y))
+    assert np.array_equal(d2.predict(y), det.predict(y)) and np.array_equal(d2.score_samples(y), det.score_samples(y))
+    assert np.array_equal(d2.support_, det.support_) and d2.offset_ == det.offset_
+
+
+def test_training_mirror_validates_detector_fit_choice(tmp_path):
+    from cellscreen.training import ImprovedAnomalyDetectionTraining
+    assert ImprovedAnomalyDetectionTraining(str(tmp_path)).detector_fit == "device"
+    assert ImprovedAnomalyDetectionTraining(str(tmp_path), detector_fit="sklearn").detector_fit == "sklearn"
+    with pytest.raises(ValueError):
+        ImprovedAnomalyDetectionTraining(str(tmp_path), detector_fit="cpu")
