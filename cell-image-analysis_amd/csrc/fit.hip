@@ -267,7 +267,7 @@ struct SmoState {
     long long n_iter;
 };
 struct SmoArgs {
-    const double* xT;    // [D][ld]
+    const void* xT;      // [D][ld], double -- or float when every training value is a float (PCA output is): same numbers, half the bytes
     const double* xsq;   // [n]
     long ld;
     int n, D, nb, pad;
@@ -282,15 +282,16 @@ struct SmoArgs {
 };
 
 // x [n][D] row-major -> xT [D][ld]; xsq[j] = x_j . x_j
+template <class XT>
 __global__ __launch_bounds__(256) void smo_prepare_kernel(const double* __restrict__ x, int n, int D, long ld,
-                                                          double* __restrict__ xT, double* __restrict__ xsq)
+                                                          XT* __restrict__ xT, double* __restrict__ xsq)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     double s = 0.0;
     for (int d = 0; d < D; ++d) {
         const double v = x[(size_t)j * D + d];
-        xT[(size_t)d * ld + j] = v;
+        xT[(size_t)d * ld + j] = (XT)v;
         s = fma(v, v, s);
     }
     xsq[j] = s;
@@ -351,8 +352,10 @@ __device__ __forceinline__ SmoPickJ reduce_pick_j(SmoPickJ p, SmoPickJ* sh /* [4
 // A thread owns point j with x_j in registers (SMO_DP doubles); x_i are staged through LDS 16 at a time and
 // read as broadcasts.  Also emits the first row-i candidates.
 constexpr int INIT_ROWS = 16;
+template <class XT>
 __global__ __launch_bounds__(SMO_B, 1) void smo_init_kernel(SmoArgs a, int n0)
 {
+    const XT* __restrict__ xT = (const XT*)a.xT;
     __shared__ double xi[INIT_ROWS][SMO_DP];
     __shared__ double xsqi[INIT_ROWS], ali[INIT_ROWS];
     __shared__ SmoPickI shp[SMO_B / 64];
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(SMO_B, 1) void smo_init_kernel(SmoArgs a, int n0)
     const int jj = j < a.n ? j : a.n - 1;
     double xj[SMO_DP];
 #pragma unroll
-    for (int d = 0; d < SMO_DP; ++d) xj[d] = d < a.D ? a.xT[(size_t)d * a.ld + jj] : 0.0;
+    for (int d = 0; d < SMO_DP; ++d) xj[d] = d < a.D ? (double)xT[(size_t)d * a.ld + jj] : 0.0;
     const double xsqj = a.xsq[jj];
     const double* alpha = a.alpha[0];
     double g = 0.0;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(SMO_B, 1) void smo_init_kernel(SmoArgs a, int n0)
         __syncthreads();
         for (int e = tid; e < INIT_ROWS * SMO_DP; e += SMO_B) {
             const int r = e / SMO_DP, d = e % SMO_DP, i = i0 + r;
-            xi[r][d] = (i < n0 && d < a.D) ? a.xT[(size_t)d * a.ld + i] : 0.0;
+            xi[r][d] = (i < n0 && d < a.D) ? (double)xT[(size_t)d * a.ld + i] : 0.0;
         }
         if (tid < INIT_ROWS) {
             const int i = i0 + tid;
@@ -397,8 +400,10 @@ __global__ __launch_bounds__(SMO_B, 1) void smo_init_kernel(SmoArgs a, int n0)
 
 // Launch 1 of an iteration: i = argmax over {alpha_t < C} of -G_t (svm.cpp:957-974), row Q_i, and the
 // second-order choice of j over {alpha_j > 0} (:981-1008) as per-workgroup partials.
+template <class XT>
 __global__ __launch_bounds__(SMO_B) void smo_row_i_kernel(SmoArgs a, int parity)
 {
+    const XT* __restrict__ xT = (const XT*)a.xT;
     __shared__ double xs[SMO_DP];
     __shared__ SmoPickI shi[SMO_B / 64];
     __shared__ SmoPickJ shj[SMO_B / 64];
@@ -423,14 +428,14 @@ __global__ __launch_bounds__(SMO_B) void smo_row_i_kernel(SmoArgs a, int parity)
         if (tid == 0) a.part_j[blockIdx.x] = SmoPickJ{SMO_INF, -SMO_INF, -1, 0};
         return;
     }
-    if (tid < a.D) xs[tid] = a.xT[(size_t)tid * a.ld + i];
+    if (tid < a.D) xs[tid] = (double)xT[(size_t)tid * a.ld + i];
     __syncthreads();
     const double xsqi = a.xsq[i];
     const int j = blockIdx.x * SMO_B + tid;
     SmoPickJ pj{SMO_INF, -SMO_INF, -1, 0};
     if (j < a.n) {
         double dot = 0.0;
-        for (int d = 0; d < a.D; ++d) dot = fma(a.xT[(size_t)d * a.ld + j], xs[d], dot);
+        for (int d = 0; d < a.D; ++d) dot = fma((double)xT[(size_t)d * a.ld + j], xs[d], dot);
         const float q = rbf_q(a.gamma, xsqi, a.xsq[j], dot);
         a.Qi[j] = q;
         if (alpha[j] > 0.0) {                                          // !is_lower_bound(j)
@@ -452,8 +457,10 @@ __global__ __launch_bounds__(SMO_B) void smo_row_i_kernel(SmoArgs a, int parity)
 
 // Launch 2: j from the partials, the stopping test (svm.cpp:1029-1030), the two-variable update (:806-845),
 // row Q_j, G += Q_i d_alpha_i + Q_j d_alpha_j (:849-855), and the next iteration's row-i candidates.
+template <class XT>
 __global__ __launch_bounds__(SMO_B) void smo_update_kernel(SmoArgs a, int parity)
 {
+    const XT* __restrict__ xT = (const XT*)a.xT;
     __shared__ double xs[SMO_DP];
     __shared__ SmoPickI shi[SMO_B / 64];
     __shared__ SmoPickJ shj[SMO_B / 64];
@@ -497,14 +504,14 @@ __global__ __launch_bounds__(SMO_B) void smo_update_kernel(SmoArgs a, int parity
         }
     }
     const double dai = __dsub_rn(ai, old_ai), daj = __dsub_rn(aj, old_aj);
-    if (tid < a.D) xs[tid] = a.xT[(size_t)tid * a.ld + j];
+    if (tid < a.D) xs[tid] = (double)xT[(size_t)tid * a.ld + j];
     __syncthreads();
     const double xsqj = a.xsq[j];
     const int k = blockIdx.x * SMO_B + tid;
     SmoPickI pi{-SMO_INF, -1, 0};
     if (k < a.n) {
         double dot = 0.0;
-        for (int d = 0; d < a.D; ++d) dot = fma(a.xT[(size_t)d * a.ld + k], xs[d], dot);
+        for (int d = 0; d < a.D; ++d) dot = fma((double)xT[(size_t)d * a.ld + k], xs[d], dot);
         const float qj = rbf_q(a.gamma, xsqj, a.xsq[k], dot);
         const double gn = __dadd_rn(G[k], __dadd_rn(__dmul_rn((double)a.Qi[k], dai), __dmul_rn((double)qj, daj)));
         const double an = k == i ? ai : (k == j ? aj : alpha[k]);
@@ -777,6 +784,14 @@ int cs_fit_ocsvm(cs_fit* f, const double* x, int64_t n, int32_t n_components, do
         (rc = f->part_j.ensure((size_t)nb * sizeof(SmoPickJ))) || (rc = f->state.ensure(sizeof(SmoState))))
         return rc;
 
+    // PCA output is float32 cast to double (sklearn svm/_base.py:190): then every value is a float and the
+    // transposed copy can be stored as such without changing a single product
+    bool as_float = true;
+    for (size_t e = 0, ne = (size_t)n * D; e < ne; ++e) {
+        if (!std::isfinite(x[e])) return fail(CS_ERR_INVALID, "x holds a non-finite value at element %zu (sklearn's check_array rejects it)", e);
+        as_float = as_float && (double)(float)x[e] == x[e];
+    }
+
     // solve_one_class, svm.cpp:1718-1735: nu_l accumulated point by point, the first points filled to C = 1
     std::vector<double> a0((size_t)n, 0.0);
     int n0 = 0;
@@ -796,16 +811,21 @@ int cs_fit_ocsvm(cs_fit* f, const double* x, int64_t n, int32_t n_components, do
     HIPCHK(hipMemsetAsync(f->state.p, 0, sizeof(SmoState), f->stream));
     Timer tm(f);
     SmoArgs a{};
-    a.xT = f->xT.as<double>(); a.xsq = f->xsq.as<double>(); a.ld = ld; a.n = N; a.D = D; a.nb = nb;
+    a.xT = f->xT.p; a.xsq = f->xsq.as<double>(); a.ld = ld; a.n = N; a.D = D; a.nb = nb;
     a.gamma = gamma; a.eps = eps; a.max_iter = max_iter;
     a.alpha[0] = f->alpha0.as<double>(); a.alpha[1] = f->alpha1.as<double>();
     a.G[0] = f->G0.as<double>(); a.G[1] = f->G1.as<double>();
     a.Qi = f->Qi.as<float>(); a.part_i = f->part_i.as<SmoPickI>(); a.part_j = f->part_j.as<SmoPickJ>();
     a.state = f->state.as<SmoState>();
-    hipLaunchKernelGGL(smo_prepare_kernel, dim3((unsigned)nb), dim3(256), 0, f->stream, f->x.as<double>(), N, D, ld, f->xT.as<double>(),
-                       f->xsq.as<double>());
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(smo_init_kernel, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, n0);
+    if (as_float) {
+        hipLaunchKernelGGL(smo_prepare_kernel<float>, dim3((unsigned)nb), dim3(256), 0, f->stream, f->x.as<double>(), N, D, ld,
+                           f->xT.as<float>(), f->xsq.as<double>());
+        hipLaunchKernelGGL(smo_init_kernel<float>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, n0);
+    } else {
+        hipLaunchKernelGGL(smo_prepare_kernel<double>, dim3((unsigned)nb), dim3(256), 0, f->stream, f->x.as<double>(), N, D, ld,
+                           f->xT.as<double>(), f->xsq.as<double>());
+        hipLaunchKernelGGL(smo_init_kernel<double>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, n0);
+    }
     HIPCHK(hipGetLastError());
 
     const long long hard_cap = 200ll * 1000 * 1000;                   // sklearn's default max_iter = -1 is unbounded
@@ -815,8 +835,13 @@ int cs_fit_ocsvm(cs_fit* f, const double* x, int64_t n, int32_t n_components, do
     int parity = 0;
     while (true) {
         for (int it = 0; it < batch; ++it) {
-            hipLaunchKernelGGL(smo_row_i_kernel, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
-            hipLaunchKernelGGL(smo_update_kernel, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
+            if (as_float) {
+                hipLaunchKernelGGL(smo_row_i_kernel<float>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
+                hipLaunchKernelGGL(smo_update_kernel<float>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
+            } else {
+                hipLaunchKernelGGL(smo_row_i_kernel<double>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
+                hipLaunchKernelGGL(smo_update_kernel<double>, dim3((unsigned)nb), dim3(SMO_B), 0, f->stream, a, parity);
+            }
             parity ^= 1;
         }
         HIPCHK(hipGetLastError());

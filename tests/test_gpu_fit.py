@@ -74,6 +74,10 @@ def test_scaler_fit_rejects_nan_and_bad_arguments(fitter):
         fitter.ocsvm(np.zeros((10, 3)), 1.0, 0.0)
     with pytest.raises(RuntimeError, match="n_components"):
         fitter.ocsvm(np.zeros((10, 129)), 1.0, 0.5)
+    bad = np.zeros((10, 3))
+    bad[4, 1] = np.inf
+    with pytest.raises(RuntimeError, match="non-finite"):
+        fitter.ocsvm(bad, 1.0, 0.5)
 
 
 def test_scaler_fit_from_device_memory(fitter):
@@ -121,10 +125,15 @@ def _libsvm_pair(fitter, x, nu, **kw):
 
 @pytest.mark.parametrize("n,d,nu", [(10, 3, 0.5), (257, 7, 0.999), (3000, 100, 0.05), (3000, 100, 0.10), (2000, 128, 0.3),
                                     (6000, 100, 0.05)])
-def test_ocsvm_fit_follows_libsvm(fitter, n, d, nu):
-    """Points in general position: the device solver picks libsvm's working sets iteration for iteration."""
+@pytest.mark.parametrize("as_float32", [False, True])
+def test_ocsvm_fit_follows_libsvm(fitter, n, d, nu, as_float32):
+    """Points in general position: the device solver picks libsvm's working sets iteration for iteration.
+    as_float32: values that are exactly floats (what PCA hands the SVM, CAE...:414-427) take the kernels that keep
+    the training set as float32 in memory; the arithmetic is the same."""
     rng = np.random.default_rng(n * 1000 + d)
     x = rng.normal(size=(n, d)) * rng.uniform(0.5, 2.0, d)
+    if as_float32:
+        x = x.astype(np.float32).astype(np.float64)
     want, got, alpha = _libsvm_pair(fitter, x, nu)
     assert got["status"] == 0 and want.fit_status_ == 0
     assert got["n_iter"] == want.n_iter_
@@ -220,3 +229,22 @@ def test_device_fit_end_to_end_scores_like_sklearn_objects(tmp_path):
         pred = objs["detectors"][name].predict(objs["features_reduced"])
         assert abs((pred == -1).mean() - nu) < 0.02
     assert all(k in timings for k in ("scaler_s", "pca_moments_s", "pca_eigh_s", "svm_moderate_iter"))
+
+
+def test_ocsvm_fit_at_twenty_thousand_points(fitter):
+    """A training set of the reference's order of magnitude (libsvm needs a few seconds for it)."""
+    rng = np.random.default_rng(11)
+    z = rng.normal(size=(20000, 12))
+    x = (z @ rng.normal(size=(12, 100)) * 0.3 + rng.normal(size=(20000, 100))).astype(np.float32).astype(np.float64)
+    want, got, alpha = _libsvm_pair(fitter, x, 0.05)
+    eps = df.SVM_TOL
+    assert got["status"] == 0
+    assert abs(got["rho"] + want.intercept_[0]) <= 2 * eps                     # the solver-tolerance bar always holds
+    assert abs(got["alpha"].sum() - 0.05 * len(x)) <= 1e-9 * len(x)
+    same_path = got["n_iter"] == want.n_iter_
+    if same_path:                                                              # and normally the path is libsvm's own
+        assert np.abs(got["alpha"] - alpha).max() <= 1e-9
+    else:
+        sv_got, sv_want = set(np.flatnonzero(got["alpha"] > 0)), set(want.support_)
+        assert len(sv_got ^ sv_want) <= 0.02 * len(sv_want)
+    print(f"n_iter {got['n_iter']} vs libsvm {want.n_iter_}; max |d alpha| {np.abs(got['alpha'] - alpha).max():.3g}")
