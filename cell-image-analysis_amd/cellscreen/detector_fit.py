@@ -31,6 +31,7 @@ from .spec import DetectorParams, OCSVMParams
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SVM_TOL = 1e-3              # OneClassSVM(tol=1e-3) default -> libsvm eps
+EIGH_THREADS = 16           # BLAS threads for the F x F eigenproblem (measured: 0.18 s at 8-16, 0.79 s at 256)
 
 
 def _write_pickles(output_dir, scaler, pca, detectors):                # :437-444
@@ -172,7 +173,14 @@ def principal_axes(scatter: np.ndarray, n_samples: int, n_components: int):
     from scipy.linalg import eigh
     F = scatter.shape[0]
     cov = scatter / max(n_samples - 1, 1)
-    w, v = eigh(cov, subset_by_index=[F - n_components, F - 1])
+    try:        # LAPACK's tridiagonalisation stops scaling at a few cores; on a 256-thread host the default pool is 4x slower
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=max(1, min(EIGH_THREADS, os.cpu_count() or 1)))   # never above the pool's initial size
+    except ImportError:
+        import contextlib
+        limit = contextlib.nullcontext()
+    with limit:
+        w, v = eigh(cov, subset_by_index=[F - n_components, F - 1])
     w, v = w[::-1], v[:, ::-1]
     comps = np.ascontiguousarray(v.T)
     idx = np.argmax(np.abs(comps), axis=1)
