@@ -248,3 +248,60 @@ def test_ocsvm_fit_at_twenty_thousand_points(fitter):
         sv_got, sv_want = set(np.flatnonzero(got["alpha"] > 0)), set(want.support_)
         assert len(sv_got ^ sv_want) <= 0.02 * len(sv_want)
     print(f"n_iter {got['n_iter']} vs libsvm {want.n_iter_}; max |d alpha| {np.abs(got['alpha'] - alpha).max():.3g}")
+
+
+def test_ocsvm_solution_satisfies_kkt_at_reference_scale(fitter):
+    """Size-independent check at the reference's training-set size (50,000 x 100; libsvm needs ~20 s there): the
+    returned alpha must be dual feasible and pass libsvm's own stopping test (svm.cpp:1029) when the gradient
+    G = Q alpha is recomputed from scratch in numpy float64 -- independent of the solver's incrementally updated G."""
+    rng = np.random.default_rng(21)
+    n, d, nu = 50000, 100, 0.05
+    z = rng.normal(size=(n, 10))
+    x = (z @ rng.normal(size=(10, d)) * 0.4 + rng.normal(size=(n, d))).astype(np.float32).astype(np.float64)
+    gamma = 1.0 / (d * x.var())
+    got = fitter.ocsvm(x, gamma, nu)
+    alpha = got["alpha"]
+    assert got["status"] == 0 and got["n_iter"] > 0
+    assert alpha.min() >= 0.0 and alpha.max() <= 1.0 and abs(alpha.sum() - nu * n) <= 1e-9 * n
+    sv = np.flatnonzero(alpha > 0)
+    xs, a = x[sv], alpha[sv]
+    sq, sqs = (x * x).sum(1), (xs * xs).sum(1)
+    g = np.empty(n)
+    for lo in range(0, n, 4096):
+        hi = min(n, lo + 4096)
+        k = np.exp(-gamma * np.maximum(sq[lo:hi, None] + sqs[None, :] - 2.0 * (x[lo:hi] @ xs.T), 0.0))
+        g[lo:hi] = k.astype(np.float32).astype(np.float64) @ a          # Qfloat rounding, as the solver sees Q
+    gmax = (-g[alpha < 1.0]).max()                                       # i-candidates: not at the upper bound
+    gmax2 = g[alpha > 0.0].max()                                         # j-candidates: not at the lower bound
+    assert gmax + gmax2 < df.SVM_TOL * 1.01, f"KKT gap {gmax + gmax2:.3e}"
+    free = (alpha > 0) & (alpha < 1)
+    assert free.any() and abs(g[free].mean() - got["rho"]) <= 1e-6 * abs(got["rho"])
+    assert abs(0.5 * (alpha @ g) - got["obj"]) <= 1e-6 * abs(got["obj"])
+    # nu-property: at most nu*n points outside (alpha = 1 are the margin errors), at least nu*n support vectors
+    assert (alpha >= 1.0).sum() <= nu * n <= len(sv)
+
+
+def test_device_fit_with_fewer_cells_than_components():
+    """n_components = min(100, F, N - 1) (:412): 60 training cells give 59 components; scikit-learn's PCA picks its exact
+    'full' solver for that shape, so both fits are deterministic and can be compared directly."""
+    w = synth.random_cae(seed=42)
+    e0 = Engine.from_weights(w, None, None)
+    feats = e0.encode(synth.blob_crops(3, 60), which=0)
+    test = e0.encode(synth.blob_crops(4, 200), which=0)
+    e0.close()
+    det, objs = df.fit_detector_device(feats)
+    det_sk, objs_sk = df.fit_detector(feats)
+    assert det.n_components == det_sk.n_components == 59
+    assert objs_sk["pca"]._fit_svd_solver == "full"
+    assert np.array_equal(det.scaler_center, det_sk.scaler_center) and np.array_equal(det.scaler_scale, det_sk.scaler_scale)
+    assert np.array_equal(det.pca_mean, det_sk.pca_mean)
+    ev, ev_sk = objs["pca"].explained_variance_, objs_sk["pca"].explained_variance_
+    assert np.allclose(ev, ev_sk, rtol=1e-3, atol=1e-5 * ev_sk[0])
+    lead = int(np.sum(ev_sk > 1e-3 * ev_sk[0]))                          # axes with a spectral gap worth the name
+    dots = np.sum(det.pca_components[:lead].astype(np.float64) * det_sk.pca_components[:lead], axis=1)
+    assert np.all(dots > 0.98), dots.min()                               # same axes, same signs
+    for name in ("Conservative", "Moderate"):
+        mine = objs["detectors"][name].decision_function(objs["pca"].transform(objs["scaler"].transform(test)))
+        ref = objs_sk["detectors"][name].decision_function(objs_sk["pca"].transform(objs_sk["scaler"].transform(test)))
+        assert np.corrcoef(mine, ref)[0, 1] > 0.995
+        assert ((mine < 0) == (ref < 0)).mean() >= 0.97
