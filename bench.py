@@ -40,6 +40,8 @@ EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0,
                  "conv5_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6") or os.environ.get("CS_NO_WINO5")) else 0.25,
                  "conv6_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6")) else 0.25,
                  "conv7_up_sigmoid_err": 4.0 / 9.0,
+                 # conv6 (1/4 of 18,874,368 MACs) and conv7 (4/9 of 1,179,648: channel contraction T = a6 W_eff, then a gather) in one kernel
+                 "conv6_conv7_fused_err": (0.25 * 18874368 + 4.0 / 9.0 * 1179648) / (18874368 + 1179648),
                  "conv2_relu_bn_pool": 1.0 if os.environ.get("CS_NO_WINOGRAD") else 4.0 / 9.0,
                  "conv3_relu_bn_pool": 1.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO3")) else 4.0 / 9.0}
 BYTES_PER_CELL = 16_384 + 18       # algorithmic: read one crop, write 4 fp32/fp64-as-results + 2 int8

@@ -27,7 +27,7 @@ const char* last_error_cstr() { return g_err.c_str(); }
 static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool",
                                             "conv4_relu_bn",      "conv5_up_relu_bn",   "conv6_up_relu_bn",
                                             "conv7_up_sigmoid_err", "scaler_pca",       "ocsvm_decision",
-                                            "finalize",           "synth_crops"};
+                                            "finalize",           "synth_crops",        "conv6_conv7_fused_err"};
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
@@ -67,6 +67,8 @@ struct cs_model {
     bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
     bool wino6 = getenv("CS_NO_WINO6") == nullptr;         // A/B knob: conv5/conv6 folded-direct instead of F(2x2,2x2) phases
     bool wino5 = getenv("CS_NO_WINO5") == nullptr;         // A/B knob: conv5 only
+    bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
+    int errparts = 4;                                      // error partial sums per cell left by the last run_convs
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
     DevBuf w7eff, b7;      // conv7: effective weights [16][32] and bias, on device
     // detector
@@ -307,7 +309,7 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
             if ((rc = m->act[l].ensure((size_t)cells * m->arch.floats[l] * sizeof(float)))) return rc;
         if ((rc = m->featE.ensure((size_t)cells * m->arch.feat() * sizeof(float)))) return rc;
         if ((rc = m->pca.ensure((size_t)cells * 256 * sizeof(float)))) return rc;
-        if ((rc = m->errpart.ensure((size_t)cells * 8 * sizeof(float)))) return rc;
+        if ((rc = m->errpart.ensure((size_t)cells * 16 * sizeof(float)))) return rc;      // up to 8 partial (sq, abs) pairs per cell
         for (int d = 0; d < 2; ++d) {
             if ((rc = m->dec[d].ensure((size_t)cells * sizeof(double)))) return rc;
             if ((rc = m->o_sc[d].ensure((size_t)cells * sizeof(double)))) return rc;
@@ -383,6 +385,7 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
         if (is_last)
             LAUNCH(K_CONV7_ERR, nc, launch_recon_err(out, x, nc, (int)a.npix, m->errpart.as<float>(), m->stream));
     }
+    m->errparts = 4;
     return CS_OK;
 }
 
@@ -390,7 +393,9 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
                      float* recon)
 {
     if (!m->arch.ref) return run_convs_generic(m, &set == &m->enc ? m->genc : m->gae, x, nc, first, last, recon);
-    for (int l = first; l <= last && l < 6; ++l) {
+    // screening needs neither a6 nor the reconstruction: conv6, conv7 and the error sums run as one kernel
+    const bool fused = m->fuse67 && m->use_wino && m->wino6 && first <= 5 && last >= 6 && !recon;
+    for (int l = first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
             LAUNCH(K_CONV1 + l, nc,
@@ -405,9 +410,16 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         LAUNCH(K_CONV1 + l, nc,
                launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, l == 4 || l == 5));
     }
-    if (last >= 6)
+    if (fused) {
+        LAUNCH(K_CONV67_FUSED, nc,
+               launch_conv67_fused(m->act[4].as<float>(), set.winoup[5].as<float>(), set.ep[5].as<float>(), x, m->w7eff.as<float>(),
+                                   m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
+        m->errparts = conv67_fused_nparts();
+    } else if (last >= 6) {
         LAUNCH(K_CONV7_ERR, nc,
                launch_conv7_err(m->act[5].as<float>(), x, m->w7eff.as<float>(), m->b7.as<float>(), m->errpart.as<float>(), recon, nc, m->stream));
+        m->errparts = 4;
+    }
     return CS_OK;
 }
 
@@ -704,7 +716,7 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
                launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
                             m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
     LAUNCH(K_FINALIZE, nc,
-           launch_finalize(with_err ? m->errpart.as<float>() : nullptr, 4, (int)m->arch.npix, m->dec[0].as<double>(),
+           launch_finalize(with_err ? m->errpart.as<float>() : nullptr, m->errparts, (int)m->arch.npix, m->dec[0].as<double>(),
                            m->dec[1].as<double>(), mse, mae, sc, sm, pc, pm, nc, m->stream));
     return CS_OK;
 }
@@ -813,7 +825,7 @@ int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, f
         float* d_mse = out_ptr(mse, out_kind, off, m->o_mse);
         float* d_mae = out_ptr(mae, out_kind, off, m->o_mae);
         LAUNCH(K_FINALIZE, nc,
-               launch_finalize(m->errpart.as<float>(), 4, (int)m->arch.npix, nullptr, nullptr, d_mse, d_mae, nullptr, nullptr,
+               launch_finalize(m->errpart.as<float>(), m->errparts, (int)m->arch.npix, nullptr, nullptr, d_mse, d_mae, nullptr, nullptr,
                                nullptr, nullptr, nc, m->stream));
         if ((rc = stage_out(m, mse, out_kind, off, nc, d_mse))) return rc;
         if ((rc = stage_out(m, mae, out_kind, off, nc, d_mae))) return rc;
@@ -969,6 +981,7 @@ int cs_profile_get(cs_model* m, int k, double* total_ms, int64_t* launches, int6
     if (flops) {
         double per_cell = 0.0;
         if (k <= K_CONV7_ERR) per_cell = 2.0 * kLayerMacs[k];
+        else if (k == K_CONV67_FUSED) per_cell = 2.0 * (kLayerMacs[5] + kLayerMacs[6]);
         else if (k == K_SCALER_PCA) per_cell = 2.0 * (double)m->F * m->C;
         else if (k == K_SVM) per_cell = 0.0;  // fp64, reported separately
         *flops = per_cell * (double)m->prof_cells[k];

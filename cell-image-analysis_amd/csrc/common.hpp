@@ -22,7 +22,7 @@ struct LayerGeom {
 // Kernel families, for cs_profile_*.
 enum KernelId {
     K_CONV1 = 0, K_CONV2, K_CONV3, K_CONV4, K_CONV5, K_CONV6, K_CONV7_ERR,
-    K_SCALER_PCA, K_SVM, K_FINALIZE, K_SYNTH, K_COUNT
+    K_SCALER_PCA, K_SVM, K_FINALIZE, K_SYNTH, K_CONV67_FUSED, K_COUNT
 };
 
 // ---- launchers (each enqueues on `stream`, returns hipGetLastError()) -------------
@@ -48,6 +48,12 @@ size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);
 
 // conv7 + sigmoid + per-cell squared/absolute error partial sums.
 // a6: [n][32][32][32]; x: [n][64][64] (the array the reconstruction is compared with);
+// conv6 + conv7 + reconstruction error fused (the screening path): a5 -> per-cell error partials
+// errpart[n][conv67_fused_nparts()][2]; neither a6 nor the reconstruction is written.
+hipError_t launch_conv67_fused(const float* a5, const float* ufrag, const float* ep, const float* x, const float* weff_dev,
+                               const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
+int conv67_fused_nparts();
+
 // weff_dev: device, [16][32] effective weights (conv7_effective_weights / launch_pack_w7eff);
 // b7_dev: device, the conv's bias; errpart: [n][4][2]; recon (may be null): [n][64][64].
 hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,

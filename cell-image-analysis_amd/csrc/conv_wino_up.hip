@@ -233,6 +233,249 @@ __global__ __launch_bounds__(C::THREADS, 2) void conv_wino_up_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv6 + conv7 + reconstruction error in one kernel (the screening path, which needs neither a6 nor the
+// reconstruction in HBM).  The conv6 part is the kernel above with a cell-major loop (a workgroup takes a whole
+// cell, its four 8-row groups in order); instead of storing a6, the epilogue leaves the group's 8 x 32 x 32 block
+// in LDS.  conv7 over the upsampled a6 is, per output phase (a,b), a 2x2-tap conv over STORED a6 pixels
+// (conv_out.hip: W_eff[a][b][ry][rx][c]); contracting the 32 channels first,
+//     T[y][x][n] = sum_c a6[y][x][c] W_eff[n][c],   n = ((a 2 + b) 2 + ry) 2 + rx          (one MFMA chain per 16 pixels)
+//     out(2y+a, 2x+b) = b7 + sum_{ry,rx} T[y+a-1+ry][x+b-1+rx][n(a,b,ry,rx)]                (4 LDS reads per output)
+// turns it into a 32 -> 16 GEMM on the matrix pipe plus a gather; T lives in a 16-row ring in LDS (a new a6 row y
+// completes output rows 2y-1 and 2y; the last row, 63, is finished after the fourth group against the zero
+// padding).  Sigmoid, (x - r)^2 and |x - r| accumulate per thread over the whole cell and leave as 8 per-wave
+// partial sums per cell, in fixed order.  Two barriers per group: after the a6 block is written, after T and the
+// next input strip are written.  One workgroup per CU (130 KB of LDS; measured: conv6 alone runs as fast with one
+// workgroup per CU as with two, the SIMDs are MFMA/VALU-bound either way).
+struct F67 {
+    using C = WUL6;
+    static constexpr int PA = 36;                              // a6 pixel stride in LDS (floats): 9 16-byte slots
+    static constexpr int A6_BYTES = 8 * 32 * PA * 4;
+    static constexpr int TWD = 34, TSLOTS = 16;                // T row: 32 columns + zero halo; 16-row ring
+    static constexpr int T_BYTES = TSLOTS * TWD * 16 * 4;
+    static constexpr int W_BYTES = 16 * 36 * 4;                // W_eff [n][36], read back as two 16-byte values per lane and group
+    static constexpr int LDS = C::LDS + A6_BYTES + T_BYTES + W_BYTES;
+    static constexpr int NPARTS = 8;                           // error partial sums per cell (one per wave)
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+// 1 / (1 + e^-v) on the transcendental unit: v_exp_f32 (2^x, 1 ulp) and v_rcp_f32 (1 ulp) -- about 2e-7 relative on the
+// reconstruction, against the 1e-5 the error sums are held to; a dozen instructions fewer per pixel than expf + IEEE divide
+// on a path where every VALU instruction is on the critical path.
+__device__ __forceinline__ float f67_sigmoid(float v)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+
+// DIAG stamps: [0] load issue, [1] transforms + MFMAs, [2] output transform + a6 block to LDS + barrier, [3] T + next strip
+// to LDS + barrier, [4] gather, sigmoid, error terms.
+template <bool DIAG>
+__global__ __launch_bounds__(WUL6::THREADS, 1) void conv67_fused_kernel(
+    const float* __restrict__ in /* a5 */, const float* __restrict__ ufrag, const float* __restrict__ ep /* [3][32] */,
+    const float* __restrict__ x /* crops [n][64][64] */, const float* __restrict__ weff /* [16][32] */,
+    const float* __restrict__ b7p, float* __restrict__ errpart /* [n][8][2] */, long n_cells,
+    unsigned long long* __restrict__ diag)
+{
+    using C = WUL6;
+    unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* a6s = (float*)(smem + C::LDS);
+    float* tb = (float*)(smem + C::LDS + F67::A6_BYTES);
+    float* wl = (float*)(smem + C::LDS + F67::A6_BYTES + F67::T_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave >> 1, wsl = wave & 1;
+    const int pa = ph >> 1, pb = ph & 1;
+    const int li = lane & 15, kq = lane >> 4;
+
+    float B[C::NB];
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) B[s] = ufrag[((size_t)wave * C::NB + s) * 64 + lane];
+    const int co = wsl * 16 + li;
+    float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+    float b7 = b7p[0];
+    asm volatile("" : "+v"(bias), "+v"(bns), "+v"(bnt), "+v"(b7));
+#pragma unroll
+    for (int s = 0; s < C::NB; ++s) asm volatile("" : "+v"(B[s]));
+
+    const int trow = li / C::TW, tcol = li % C::TW;
+    const int poff = ((2 * trow + pa) * C::WP + 2 * tcol + pb) * C::PS + 4 * kq;
+    const long first = blockIdx.x;
+    if (first >= n_cells) return;
+    const int se = tid & (C::EPR - 1), rsub = tid / C::EPR;
+    const int spx = se / C::C4, sc4 = se & (C::C4 - 1);
+    const int goff = spx * C::CIN + sc4 * 4;
+    const int loff = (spx + 1) * C::PS + sc4 * 4;
+    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::HS * C::WS * C::CIN; };
+    for (int i = tid; i < F67::LDS / 16; i += C::THREADS) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    wl[(tid >> 5) * 36 + (tid & 31)] = weff[tid];                  // [n][c], 512 floats, padded rows
+#pragma unroll
+    for (int j = 0; j < C::NLD; ++j) wu_store<C>((float*)smem, 0, j, rsub, loff, wu_load<C>(cell_ptr(first), 0, j, rsub, goff));
+    __syncthreads();
+
+    int buf = 0;
+    for (long cell = first; cell < n_cells; cell += gridDim.x) {
+        const float* xc = x + (size_t)cell * 64 * 64;
+        float s2 = 0.0f, s1 = 0.0f;
+#pragma unroll 1
+        for (int grp = 0; grp < C::NGRP; ++grp) {
+            const long ncell = grp < C::NGRP - 1 ? cell : cell + gridDim.x;
+            const int ngrp = grp < C::NGRP - 1 ? grp + 1 : 0;
+            const bool has_next = ncell < n_cells;
+            const float* strip = (const float*)(smem + buf * C::STRIP);
+            float* nstrip = (float*)(smem + (buf ^ 1) * C::STRIP);
+
+            if constexpr (DIAG) dt = wu_stamp();
+            f32x4 stg[C::NLD];
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(cell_ptr(ncell), ngrp * C::SR, j, rsub, goff);
+            }
+            // the crop pixels this thread's outputs are compared with (unconditional, clamped loads)
+            float xv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = wave + 8 * h, o = 2 * (8 * grp + (k >> 1)) - 1 + (k & 1);
+                xv[h] = xc[(o < 0 ? 0 : o) * 64 + lane];
+            }
+            float xtail = 0.0f;
+            if (grp == C::NGRP - 1 && wave == 0) xtail = xc[63 * 64 + lane];
+
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[0] += t - dt; dt = t; }
+            // ---- conv6: transforms + MFMAs, as in conv_wino_up_kernel
+            const float* d0 = strip + poff;
+            f32x4 acc[9];
+#pragma unroll
+            for (int xx = 0; xx < 9; ++xx) acc[xx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 w[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 p0 = *(const f32x4*)(d0 + (0 * C::WP + c) * C::PS + 16 * q);
+                    const f32x4 p1 = *(const f32x4*)(d0 + (1 * C::WP + c) * C::PS + 16 * q);
+                    const f32x4 p2 = *(const f32x4*)(d0 + (2 * C::WP + c) * C::PS + 16 * q);
+                    w[0][c] = p0 - p1;
+                    w[1][c] = p1;
+                    w[2][c] = p1 - p2;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 v[3] = {w[r][0] - w[r][1], w[r][1], w[r][1] - w[r][2]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            acc[3 * r + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][j], B[(3 * r + c) * C::KS + 4 * q + j], acc[3 * r + c], 0, 0, 0);
+                }
+            }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(acc[0][0]), "v"(acc[8][3]));
+                const unsigned long long t = wu_stamp(); dg[1] += t - dt; dt = t;
+            }
+            // ---- Y = A^T M A, bias -> relu -> BN; the group's a6 block goes to LDS: local row 2 (2 (t / 8) + u) + a
+            auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m00 = acc[0][r], m01 = acc[1][r], m02 = acc[2][r];
+                const float m10 = acc[3][r], m11 = acc[4][r], m12 = acc[5][r];
+                const float m20 = acc[6][r], m21 = acc[7][r], m22 = acc[8][r];
+                const float t00 = m00 + m10, t01 = m01 + m11, t02 = m02 + m12;
+                const float t10 = m10 - m20, t11 = m11 - m21, t12 = m12 - m22;
+                const float y00 = t00 + t01, y01 = t01 - t02, y10 = t10 + t11, y11 = t11 - t12;
+                const int t = 4 * kq + r;
+                const int lr = 4 * (t / C::TW) + pa, lc = 4 * (t % C::TW) + pb;        // (u,v) = (0,0)
+                float* o = a6s + (lr * 32 + lc) * F67::PA + co;
+                o[0] = post(y00);
+                o[2 * F67::PA] = post(y01);                                            // column + 2
+                o[2 * 32 * F67::PA] = post(y10);                                       // row + 2
+                o[(2 * 32 + 2) * F67::PA] = post(y11);
+            }
+            __syncthreads();
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[2] += t - dt; dt = t; }
+            // ---- T = a6 W_eff^T for local row `wave`, 16 pixels per MFMA chain; K order: channel 8 kq + s
+            float wc[8];                                                                 // W_eff[n = li][c = 8 kq + s]
+            *(f32x4*)&wc[0] = *(const f32x4*)(wl + li * 36 + kq * 8);
+            *(f32x4*)&wc[4] = *(const f32x4*)(wl + li * 36 + kq * 8 + 4);
+            {
+                const float* ap = a6s + ((wave * 32 + li) * F67::PA + kq * 8);
+                const f32x4 a00 = *(const f32x4*)ap, a01 = *(const f32x4*)(ap + 4);
+                const f32x4 a10 = *(const f32x4*)(ap + 16 * F67::PA), a11 = *(const f32x4*)(ap + 16 * F67::PA + 4);
+                f32x4 t0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;                     // two independent chains, interleaved
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[s], wc[s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[s], wc[s], t1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
+                }
+                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * F67::TWD) + 4 * kq + 1) * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { tw[r * 16] = t0[r]; tw[(16 + r) * 16] = t1[r]; }
+            }
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < C::NLD; ++j) wu_store<C>(nstrip, ngrp * C::SR, j, rsub, loff, stg[j]);
+            }
+            __syncthreads();
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
+            // ---- gather: new a6 row y finishes output rows 2y - 1 (phase a = 1 of row y - 1) and 2y (a = 0)
+            const int px = lane & 1, xh = (lane >> 1) + px;                              // halo column of rx = 0
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = wave + 8 * h;                                              // wave-uniform
+                const int y = 8 * grp + (k >> 1), e = k & 1;
+                if (2 * y - 1 + e < 0) continue;
+                const int nb = ((1 - e) * 2 + px) * 4;
+                const float* ra = tb + (((y - 1) & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
+                const float* rb = tb + ((y & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
+                float ta0 = ra[0], ta1 = ra[16 + 1];
+                const float tb0 = rb[2], tb1 = rb[16 + 3];
+                if (y == 0) { ta0 = 0.0f; ta1 = 0.0f; }                                  // row -1: zero padding
+                const float v = ((ta0 + ta1) + (tb0 + tb1)) + b7;
+                const float rr = f67_sigmoid(v);
+                const float d = xv[h] - rr;
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+            }
+            if (grp == C::NGRP - 1 && wave == 0) {                                      // output row 63: a6 row 31 and the padding
+                const int nb = (2 + px) * 4;
+                const float* ra = tb + ((31 & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
+                const float v = (ra[0] + ra[16 + 1]) + b7;
+                const float rr = f67_sigmoid(v);
+                const float d = xtail - rr;
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+            }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(s2), "v"(s1));
+                const unsigned long long t = wu_stamp(); dg[4] += t - dt; dt = t;
+            }
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_down(s2, off, 64);
+            s1 += __shfl_down(s1, off, 64);
+        }
+        if (lane == 0) {
+            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 0] = s2;
+            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 1] = s1;
+        }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) diag[((size_t)blockIdx.x * 8 + wave) * 5 + k] = dg[k];
+        }
+    }
+}
+
 // U = G W_eff G^T per (phase, cin, cout), evaluated in double and rounded once.
 // Layout [wave = phase * 2 + half][(k * 9 + xi) * KS + 4 q + j][lane]:
 //   U[xi = 3 r + c][ci = 16 q + 4 kq + j][co = 16 (half * NSW + k) + li].
@@ -273,15 +516,16 @@ hipError_t launch(int layer, const float* in, const float* ufrag, const float* e
 {
     static int resident = 0;
     static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
+    static const int LDSB = getenv("CS_WU_LDS") ? atoi(getenv("CS_WU_LDS")) : C::LDS;   // experiment: more LDS = fewer workgroups per CU
     if (!resident) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_up_kernel<C, false>, C::THREADS, C::LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_wino_up_kernel<C, false>, C::THREADS, LDSB);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
@@ -294,15 +538,46 @@ hipError_t launch(int layer, const float* in, const float* ufrag, const float* e
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     if (diag)
-        hipLaunchKernelGGL((conv_wino_up_kernel<C, true>), dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+        hipLaunchKernelGGL((conv_wino_up_kernel<C, true>), dim3(grid), dim3(C::THREADS), LDSB, stream, in, ufrag, ep, out, (long)n_cells,
                            g_wu_diag[layer]);
     else
-        hipLaunchKernelGGL((conv_wino_up_kernel<C, false>), dim3(grid), dim3(C::THREADS), C::LDS, stream, in, ufrag, ep, out, (long)n_cells,
+        hipLaunchKernelGGL((conv_wino_up_kernel<C, false>), dim3(grid), dim3(C::THREADS), LDSB, stream, in, ufrag, ep, out, (long)n_cells,
                            (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
 }  // namespace
+
+int conv67_fused_nparts() { return F67::NPARTS; }
+
+hipError_t launch_conv67_fused(const float* a5, const float* ufrag, const float* ep, const float* x, const float* weff_dev,
+                               const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream)
+{
+    static int cus = 0;
+    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
+    if (!cus) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv67_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F67::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv67_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F67::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (diag) {                                                // slot 3 of the diagnostic table: the fused kernel
+            if ((e = hipMalloc(&g_wu_diag[3], (size_t)cus * 40 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_wu_diag_blocks[3] = cus;
+        }
+    }
+    if (n_cells <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);
+    if (diag)
+        hipLaunchKernelGGL(conv67_fused_kernel<true>, dim3(grid), dim3(WUL6::THREADS), F67::LDS, stream, a5, ufrag, ep, x, weff_dev, b7_dev,
+                           errpart, (long)n_cells, g_wu_diag[3]);
+    else
+        hipLaunchKernelGGL(conv67_fused_kernel<false>, dim3(grid), dim3(WUL6::THREADS), F67::LDS, stream, a5, ufrag, ep, x, weff_dev, b7_dev,
+                           errpart, (long)n_cells, (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
 
 size_t pack_wino_up_fragments(int layer, const float* hwio, float* dst)
 {
@@ -323,7 +598,7 @@ hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, c
 extern "C" int cs_debug_wino_up_diag(int layer, double out5[5])
 {
     using namespace cs;
-    if (layer < 4 || layer > 5 || !g_wu_diag[layer]) return -1;
+    if (layer < 3 || layer > 5 || !g_wu_diag[layer]) return -1;    // 3: the fused conv6 + conv7 kernel
     if (hipDeviceSynchronize() != hipSuccess) return -2;
     const size_t n = (size_t)g_wu_diag_blocks[layer] * 40;
     unsigned long long* h = new unsigned long long[n];

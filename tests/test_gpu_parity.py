@@ -291,3 +291,25 @@ def test_scaler_is_bit_exact_through_one_hot_pca(weights, det):
     t = (x[:, cols] - d.scaler_center[cols]).astype(np.float32)
     want = (t.astype(np.float64) / d.scaler_scale[cols]).astype(np.float32)
     assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} scaled values differ"
+
+
+def test_fused_conv6_conv7_error_matches_the_two_kernel_path(engine, weights):
+    """cs_screen / cs_reconstruct without a reconstruction buffer run conv6 + conv7 + the error sums as ONE kernel (a6
+    and the reconstruction never reach HBM; conv7 as a 32 -> 16 channel contraction plus a gather, hardware exp2 / rcp
+    sigmoid); with a reconstruction buffer the two separate kernels run.  Same numbers up to fp32 summation order:
+    1e-6 relative on MSE / MAE (the oracle bar for either is 1e-5)."""
+    from oracle import oracle as orc
+    for n in (1, 255, 256, 257, 1500):                     # below, at and above one cell per CU; a ragged tail
+        x = synth.synth_crops(9, 1000, n)
+        x[0] = 0.0
+        if n > 2:
+            x[1] = 1.0
+            x[2, :, ::2] = 0.0                             # stripes: every phase / halo column of the gather matters
+        _, mse_f, mae_f = engine.reconstruct(x, want_recon=False)
+        rec, mse_u, mae_u = engine.reconstruct(x, want_recon=True)
+        assert np.abs(mse_f - mse_u).max() <= 1e-6 * np.abs(mse_u).max()
+        assert np.abs(mae_f - mae_u).max() <= 1e-6 * np.abs(mae_u).max()
+        if n <= 257:
+            ref = orc.cae_forward(weights, x, acc64=True, want=("mse", "mae"))
+            assert np.abs(mse_f - ref["mse"]).max() <= 1e-5 * np.abs(ref["mse"]).max()
+            assert np.abs(mae_f - ref["mae"]).max() <= 1e-5 * np.abs(ref["mae"]).max()

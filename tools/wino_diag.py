@@ -34,7 +34,8 @@ for layer, groups in ((1, 16), (2, 4)):
         print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
 
 # the F(2x2,2x2) phase kernels of conv5 / conv6 (one 512-thread workgroup per CU)
-f = e.reconstruct(x, want_recon=False)
+f = e.reconstruct(x, want_recon=True)     # with the reconstruction asked for, conv6 and conv7 run as separate kernels
+del f
 prof = e.profile()
 names5 = ["load issue", "transform+MFMA", "epilogue+stores", "strip writes", "barrier"]
 for layer, groups in ((5, 4), (4, 1)):
@@ -46,3 +47,15 @@ for layer, groups in ((5, 4), (4, 1)):
     print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608)")
     for n_, a in zip(names5, v):
         print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
+
+# the fused conv6 + conv7 + error kernel (slot 3), one workgroup per CU, 4 groups per cell
+f = e.reconstruct(x, want_recon=False)
+names67 = ["load issue", "transform+MFMA", "out transform+a6->LDS+barrier", "T+strip writes+barrier", "gather+sigmoid+err"]
+out = (C.c_double * 5)()
+rc = lib.cs_debug_wino_up_diag(3, out)
+v = list(out)
+tot = sum(v)
+items = N * 4 / 256
+print(f"conv6+7 fused: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608 + 512)")
+for n_, a in zip(names67, v):
+    print(f"    {n_:30s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
