@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -- pyt
 python bench_preprocess.py > "$OUT/preprocess_bench.json" 2> "$OUT/preprocess_bench.err"
 python tools/bench_host_path.py > "$OUT/host_path.json" 2> "$OUT/host_path.err"
 python tools/bench_variant.py > "$OUT/large_variant_bench.json" 2> "$OUT/large_variant_bench.err"
+python tools/bench_fit.py --n 50000 > "$OUT/fit_bench.json" 2> "$OUT/fit_bench.err"
 
 cp "$OUT/bench.json" "profiles/${TAG}_bench.json"
 cp "$OUT/bench_under_rocprof.json" "profiles/${TAG}_bench_under_rocprof.json"
@@ -32,4 +33,5 @@ cp "$(ls "$OUT"/prof_train/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_tra
 cp "$OUT/preprocess_bench.json" "profiles/${TAG}_preprocess_bench.json"
 cp "$OUT/host_path.json" "profiles/${TAG}_host_path.json"
 cp "$OUT/large_variant_bench.json" "profiles/${TAG}_large_variant_bench.json"
+cp "$OUT/fit_bench.json" "profiles/${TAG}_fit_bench.json"
 echo "profiles/${TAG}_* refreshed; add the rows to profiles/README.md"
