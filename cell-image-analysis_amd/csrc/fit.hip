@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void keys_transpose_kernel(const float* __rest
 {
     __shared__ unsigned tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
-    const long r0 = (long)blockIdx.y * 32;
-    const int c0 = blockIdx.x * 32;
+    const long r0 = (long)blockIdx.x * 32;                             // rows on grid.x (no 65,535 limit), feature tiles on grid.y
+    const int c0 = blockIdx.y * 32;
     int nans = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -609,7 +609,7 @@ int check_features(const cs_fit* f, const float* features, int64_t n, int F, int
     if (!features) return fail(CS_ERR_INVALID, "features is NULL");
     if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "memory kind must be CS_MEM_HOST or CS_MEM_DEVICE");
     if (n < 1 || n > (1ll << 30)) return fail(CS_ERR_INVALID, "n=%lld: need 1 .. 2^30 training cells", (long long)n);
-    if (F < 1 || F > (1 << 20)) return fail(CS_ERR_INVALID, "n_features=%d out of range", F);
+    if (F < 1 || F > (1 << 20)) return fail(CS_ERR_INVALID, "n_features=%d out of range (1 .. 2^20)", F);
     return CS_OK;
 }
 
@@ -664,7 +664,7 @@ int cs_fit_scaler(cs_fit* f, const float* features, int64_t n, int32_t n_feature
 
     Timer tm(f);
     HIPCHK(hipMemsetAsync(f->nanc.p, 0, sizeof(int), f->stream));
-    hipLaunchKernelGGL(keys_transpose_kernel, dim3((unsigned)((F + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, f->stream,
+    hipLaunchKernelGGL(keys_transpose_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((F + 31) / 32)), dim3(256), 0, f->stream,
                        d_feat, (long)n, F, ld, f->keys.as<unsigned>(), f->nanc.as<int>());
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(column_select_kernel, dim3((unsigned)F), dim3(SEL_THREADS), 0, f->stream, f->keys.as<unsigned>(), (long)n, ld,

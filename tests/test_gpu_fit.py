@@ -305,3 +305,13 @@ def test_device_fit_with_fewer_cells_than_components():
         ref = objs_sk["detectors"][name].decision_function(objs_sk["pca"].transform(objs_sk["scaler"].transform(test)))
         assert np.corrcoef(mine, ref)[0, 1] > 0.995
         assert ((mine < 0) == (ref < 0)).mean() >= 0.97
+
+
+def test_scaler_fit_with_millions_of_rows(fitter):
+    """More than 65,535 row tiles (the grid.y limit the transpose kernel must not depend on)."""
+    from sklearn.preprocessing import RobustScaler
+    rng = np.random.default_rng(77)
+    x = rng.gamma(2.0, 1.0, (2_200_000, 8)).astype(np.float32)
+    want = RobustScaler().fit(x)
+    center, scale = fitter.scaler(x)
+    assert np.array_equal(center, want.center_) and np.array_equal(scale, want.scale_)
