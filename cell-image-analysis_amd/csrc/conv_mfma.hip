@@ -214,7 +214,6 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     const long total = n_cells * C::NSTRIP;
     const long first = blockIdx.x;
     if (first >= total) return;
-
     // ---- prologue: first strip ---------------------------------------------------------
     elem_t stg[C::MODE == STAGE_PF ? C::NLD : C::LPP];
     if constexpr (C::MODE == STAGE_PF) {
@@ -248,6 +247,45 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         }
         const char* strip = smem + (C::MODE == STAGE_DB ? buf * C::STRIP_BYTES : 0);
         char* nstrip = smem + (C::MODE == STAGE_DB ? (buf ^ 1) * C::STRIP_BYTES : 0);
+
+        // ---- epilogue pieces shared by the pair loops: D[row = 4*kq + r][col = li] -> per-mode transform
+        auto post = [&](float v) -> float {
+            if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) return relu_bn(v, bias, bns, bnt);
+            else if constexpr (C::EPI == EPI_RELU) return fmaxf(v + bias, 0.0f);
+            else return v;
+        };
+        // pooled store of a tile pair (rows y, y+1; the lane holds pixels x..x+3 of both): two outputs at o, o + COUT
+        // (the wave-uniform all_up test is a template argument so that an unrolled caller can hoist it out of its loop)
+        auto pooled_store_t = [&](auto allup_c, const f32x4& acc0, const f32x4& acc1, float* o) {
+            if constexpr (C::EPI == EPI_SUMPOOL) {
+                o[0] = (acc0[0] + acc0[1]) + (acc1[0] + acc1[1]);
+                o[C::COUT] = (acc0[2] + acc0[3]) + (acc1[2] + acc1[3]);
+            } else {
+                // MaxPooling2D after bias -> ReLU -> BN: that map is monotone (non-decreasing where the BN
+                // scale is >= 0, non-increasing where it is negative), so the max over the window of the
+                // mapped values is the map of the window's max (resp. min) of the raw sums -- the same bits
+                // for a third of the epilogue's VALU work
+                // raw v_max / v_min (fmaxf would first canonicalise each operand with a v_max x, x)
+                auto vmax = [](float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+                auto vmin = [](float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+                if constexpr (decltype(allup_c)::value) {   // every channel of this wave has a non-negative BN scale (wave-uniform, the usual case)
+                    o[0] = post(vmax(vmax(acc0[0], acc0[1]), vmax(acc1[0], acc1[1])));
+                    o[C::COUT] = post(vmax(vmax(acc0[2], acc0[3]), vmax(acc1[2], acc1[3])));
+                } else {
+                    const bool up = bns >= 0.0f;
+                    auto ext = [&](float a, float b, float c, float d) {
+                        const float mx = vmax(vmax(a, b), vmax(c, d)), mn = vmin(vmin(a, b), vmin(c, d));
+                        return up ? mx : mn;
+                    };
+                    o[0] = post(ext(acc0[0], acc0[1], acc1[0], acc1[1]));
+                    o[C::COUT] = post(ext(acc0[2], acc0[3], acc1[2], acc1[3]));
+                }
+            }
+        };
+        auto pooled_store = [&](const f32x4& acc0, const f32x4& acc1, float* o) {
+            if (all_up) pooled_store_t(std::true_type{}, acc0, acc1, o);
+            else pooled_store_t(std::false_type{}, acc0, acc1, o);
+        };
 
         // ---- folded upsample conv: phase-pure tile pairs ((a,0),(a,1)) over stored pixels -------
         if constexpr (C::FOLD) {
@@ -321,6 +359,34 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                     }
                 }
             }
+        } else if constexpr (C::CIN == 1 && C::POOL && C::W >= 16 && C::TPR % C::NMG == 0 && C::MODE == STAGE_PF) {
+        // ---- conv1 (and its transposed twin in training): the 16 tile pairs of a wave, fully unrolled.  Pair
+        // p = mg + NMG it sits at tile row 2 ((NMG it) / TPR), tile column (NMG it) % TPR + mg: with the loop unrolled
+        // everything but mg is a constant, so LDS reads and stores take one base register + immediate offsets.  The
+        // rolled loop spent as many scalar and address instructions per pair as it has MFMAs' worth of issue time
+        // (PMC: 5.2 k SALU + 6.1 k VALU against 1.5 k MFMA per cell) on div/mod of the pair index.
+        {
+            const char* lbase = strip + (16 * mg + li) * 4;
+            float* obase = out + (((size_t)cell * C::HO + (y0 >> 1)) * C::WO + 8 * mg + 2 * kq) * C::COUT + co;
+            auto pairs = [&](auto allup_c) {
+#pragma unroll
+                for (int it = 0; it < C::PPW; ++it) {
+                    const int pq = C::NMG * it, ry = 2 * (pq / C::TPR), xq = pq % C::TPR;
+                    const char* a = lbase + (ry * C::WP + 16 * xq) * 4;
+                    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const float a0 = *(const float*)(a + toff[s]);
+                        const float a1 = *(const float*)(a + toff[s] + C::WP * 4);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B[s], acc1, 0, 0, 0);
+                    }
+                    pooled_store_t(allup_c, acc0, acc1, obase + ((size_t)(ry / 2) * C::WO + 8 * xq) * C::COUT);
+                }
+            };
+            if (all_up) pairs(std::true_type{});
+            else pairs(std::false_type{});
+        }
         } else {
         // ---- tile pairs ----------------------------------------------------------
         int pi = 0;
@@ -398,11 +464,6 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
             }
 
             // ---- epilogue: D[row = 4*kq + r][col = li] -> per-mode transform, store
-            auto post = [&](float v) -> float {
-                if constexpr (C::EPI == EPI_BN || C::EPI == EPI_BN_POOL) return relu_bn(v, bias, bns, bnt);
-                else if constexpr (C::EPI == EPI_RELU) return fmaxf(v + bias, 0.0f);
-                else return v;
-            };
             if constexpr (C::POOL) {
                 // lane holds pixels x = xq..xq+3 of rows (y, y+1); t0/t1 share columns
                 int qy, qx;
@@ -410,30 +471,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 const int yo = (y0 + qy) >> 1;
                 const int xo = qx >> 1;
                 float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
-                if constexpr (C::EPI == EPI_SUMPOOL) {
-                    o[0] = (acc0[0] + acc0[1]) + (acc1[0] + acc1[1]);
-                    o[C::COUT] = (acc0[2] + acc0[3]) + (acc1[2] + acc1[3]);
-                } else {
-                    // MaxPooling2D after bias -> ReLU -> BN: that map is monotone (non-decreasing where the BN
-                    // scale is >= 0, non-increasing where it is negative), so the max over the window of the
-                    // mapped values is the map of the window's max (resp. min) of the raw sums -- the same bits
-                    // for a third of the epilogue's VALU work
-                    // raw v_max / v_min (fmaxf would first canonicalise each operand with a v_max x, x)
-                    auto vmax = [](float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
-                    auto vmin = [](float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
-                    if (all_up) {   // every channel of this wave has a non-negative BN scale (wave-uniform, the usual case)
-                        o[0] = post(vmax(vmax(acc0[0], acc0[1]), vmax(acc1[0], acc1[1])));
-                        o[C::COUT] = post(vmax(vmax(acc0[2], acc0[3]), vmax(acc1[2], acc1[3])));
-                    } else {
-                        const bool up = bns >= 0.0f;
-                        auto ext = [&](float a, float b, float c, float d) {
-                            const float mx = vmax(vmax(a, b), vmax(c, d)), mn = vmin(vmin(a, b), vmin(c, d));
-                            return up ? mx : mn;
-                        };
-                        o[0] = post(ext(acc0[0], acc0[1], acc1[0], acc1[1]));
-                        o[C::COUT] = post(ext(acc0[2], acc0[3], acc1[2], acc1[3]));
-                    }
-                }
+                pooled_store(acc0, acc1, o);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-kernel SQ instruction counters from rocprofv3 PMC passes of bench.py (one directory per pass; counters that do
+not fit one pass go into separate passes, --kernel-trace only):
+
+    rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA \\
+        --output-format csv -d gpurun_out/pmc_sq1 -- python3 bench.py --steps 1 --warmup 0 --cells 131072 --no-cpu-baseline
+    python tools/pmc_sq.py gpurun_out/pmc_sq1 [more pass dirs ...] > profiles/rNN_sq_counters.json
+
+Values are per full-chunk launch, summed over the device.  SQ_INSTS_VALU counts MFMAs too; the derived field
+simd_cycles_mfma_plus_valu = 32 x MFMA + 4 x (VALU - MFMA) is the issue time of the launch if MFMA and VALU
+instructions never overlap (SQ_VALU_MFMA_COEXEC_CYCLES says they do not), and dividing it by the 1,024 SIMDs and the
+launch time gives the clock the chip would need to be fully busy."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+from pmc_traffic import KERNELS
+
+N_SIMD = 256 * 4
+
+
+def main():
+    out = collections.defaultdict(dict)
+    for d in sys.argv[1:]:
+        rows = list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])))
+        by = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            by[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for pat, name in KERNELS:
+            for k, counters in by.items():
+                if pat not in k:
+                    continue
+                for c, v in counters.items():
+                    longest = max(x[1] for x in v)
+                    full = [x for x in v if x[1] > 0.7 * longest]
+                    out[name][c] = round(sum(x[0] for x in full) / len(full))
+                    out[name]["launch_ms_under_pmc"] = round(sum(x[1] for x in full) / len(full) / 1e6, 3)
+    for name, c in out.items():
+        if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c:
+            cyc = 32 * c["SQ_INSTS_MFMA"] + 4 * (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"])
+            c["simd_cycles_mfma_plus_valu"] = cyc
+            c["implied_clock_ghz_if_fully_busy"] = round(cyc / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3) / 1e9, 3)
+    print(json.dumps({"note": "see tools/pmc_sq.py", "kernels": out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
