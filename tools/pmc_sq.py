@@ -13,6 +13,7 @@ launch time gives the clock the chip would need to be fully busy."""
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -24,7 +25,7 @@ N_SIMD = 256 * 4
 def main():
     out = collections.defaultdict(dict)
     for d in sys.argv[1:]:
-        rows = list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])))
+        rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)   # the newest pass if the directory was reused)))
         by = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
             by[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))

@@ -14,6 +14,7 @@ launches are used (the detector-fit encode pass and the tail chunk are filtered 
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -25,7 +26,7 @@ KERNELS = [("ConvCfg<64, 64, 1, 32, 1", "conv1_relu_bn_pool"), ("ConvCfg<32, 32,
 
 
 def per_kernel(d, counter, chunk):
-    rows = list(csv.DictReader(open(glob.glob(d + "/*/*_counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)   # the newest pass if the directory was reused)))
     by = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter:

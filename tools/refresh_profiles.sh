@@ -6,6 +6,7 @@
 set -euo pipefail
 TAG=${1:?usage: refresh_profiles.sh <tag>}
 OUT=gpurun_out/$TAG
+rm -rf "$OUT"        # a reused tag must not mix passes (gpurun merges the box's gpurun_out/ into the local one: clear that too)
 mkdir -p "$OUT" profiles
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 
@@ -26,10 +27,10 @@ python tools/bench_fit.py --n 50000 > "$OUT/fit_bench.json" 2> "$OUT/fit_bench.e
 
 cp "$OUT/bench.json" "profiles/${TAG}_bench.json"
 cp "$OUT/bench_under_rocprof.json" "profiles/${TAG}_bench_under_rocprof.json"
-cp "$(ls "$OUT"/prof/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_kernel_stats.csv"
+cp "$(ls -t "$OUT"/prof/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_kernel_stats.csv"
 python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" 65536 > "profiles/${TAG}_pmc_traffic.json"
 cp "$OUT/train_bench.json" "profiles/${TAG}_train_bench.json"
-cp "$(ls "$OUT"/prof_train/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_train_kernel_stats.csv"
+cp "$(ls -t "$OUT"/prof_train/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_train_kernel_stats.csv"
 cp "$OUT/preprocess_bench.json" "profiles/${TAG}_preprocess_bench.json"
 cp "$OUT/host_path.json" "profiles/${TAG}_host_path.json"
 cp "$OUT/large_variant_bench.json" "profiles/${TAG}_large_variant_bench.json"
