@@ -25,7 +25,8 @@ N_SIMD = 256 * 4
 def main():
     out = collections.defaultdict(dict)
     for d in sys.argv[1:]:
-        rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)   # the newest pass if the directory was reused)))
+        # the newest pass if the directory was reused
+        rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime))))
         by = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
             by[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))

@@ -26,7 +26,8 @@ KERNELS = [("ConvCfg<64, 64, 1, 32, 1", "conv1_relu_bn_pool"), ("ConvCfg<32, 32,
 
 
 def per_kernel(d, counter, chunk):
-    rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)   # the newest pass if the directory was reused)))
+    # the newest pass if the directory was reused
+    rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime))))
     by = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter:
