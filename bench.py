@@ -131,12 +131,18 @@ def main():
                cons_score=torch.empty(n_local, dtype=torch.float64, device=dev), mod_score=torch.empty(n_local, dtype=torch.float64, device=dev),
                cons_pred=torch.empty(n_local, dtype=torch.int8, device=dev), mod_pred=torch.empty(n_local, dtype=torch.int8, device=dev))
 
+    # the 18 B/cell of results end on rank 0's host: pinned destination buffers, one async copy per field
+    host = {k: torch.empty(n_total, dtype=v.dtype, pin_memory=True) for k, v in out.items()} if rank == 0 else None
+
     def step():
         eng.screen(x, out=out, out_device=True)
-        if world > 1:
-            g = csdist.gather_results(out, n_total, dst=0)
-            return {k: v.cpu() for k, v in g.items()} if rank == 0 else None
-        return {k: v.cpu() for k, v in out.items()}                # 18 B/cell back on the host
+        g = csdist.gather_results(out, n_total, dst=0) if world > 1 else out
+        if rank != 0:
+            return None
+        for k, v in g.items():
+            host[k].copy_(v, non_blocking=True)
+        torch.cuda.current_stream().synchronize()                   # the step ends when the results are on the host
+        return host
 
     def fence():
         if world > 1:
