@@ -77,7 +77,7 @@ struct cs_model {
     DevBuf center, scale, comps, mean_proj;
     struct Svm { DevBuf svT, svn, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
     // workspace (per chunk)
-    int64_t chunk = 16384;
+    int64_t chunk = 0;     // cells per internal pass; 0 = automatic (eff_chunk), otherwise what cs_model_set_chunk asked for
     int64_t ws_cells = 0;
     DevBuf xin, xin2, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
     // profiling
@@ -298,6 +298,21 @@ static int pack_svm(cs_model::Svm& s, const cs_ocsvm_params& p, int D, const cha
     int rc = upload(s.svT, svT.data(), svT.size() * sizeof(double));
     if (rc) return rc;
     return upload(s.coef, coef.data(), coef.size() * sizeof(double));
+}
+
+// Cells per internal pass.  Unless the caller fixed it (cs_model_set_chunk): host input streams through two staging
+// buffers and is fastest in 16,384-cell chunks (the first copy is the only exposed one); device-resident input takes
+// as many cells per pass as a ~28 GB workspace holds, up to 65,536 -- measured on the reference graph: 2.46 / 2.57 /
+// 2.58 / 2.60 M cells/s at 16,384 / 32,768 / 65,536 / 131,072 (the detector-tail kernels want >> 256 workgroups).
+static int64_t eff_chunk(const cs_model* m, int in_kind)
+{
+    if (m->chunk > 0) return m->chunk;
+    if (in_kind == CS_MEM_HOST) return 16384;
+    size_t per_cell = m->arch.npix * sizeof(float);
+    for (int l = 0; l < m->arch.n_conv - 1; ++l) per_cell += m->arch.floats[l] * sizeof(float);
+    int64_t c = (int64_t)((size_t)28e9 / (per_cell ? per_cell : 1));
+    c = c / 1024 * 1024;
+    return c < 1024 ? 1024 : (c > 65536 ? 65536 : c);
 }
 
 static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
@@ -693,7 +708,7 @@ int cs_model_get_info(const cs_model* m, cs_model_info* info)
     info->shared_encoder = m->shared_encoder ? 1 : 0;
     info->has_detector = m->has_det ? 1 : 0;
     info->device_id = m->device;
-    info->chunk_cells = m->chunk;
+    info->chunk_cells = eff_chunk(m, CS_MEM_DEVICE);
     return CS_OK;
 }
 
@@ -731,7 +746,8 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
     if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_screen needs detector parameters");
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, crops_kind);
+    const int64_t ch = n < cc ? n : cc;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
     // Host crops: two staging buffers; the H2D copy of chunk i+1 runs on its own stream while chunk i
     // computes (PCIe at ~50 GB/s carries 3 M cells/s, so the copy hides behind the kernels).  Host results
@@ -813,7 +829,8 @@ int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, f
     if (n == 0) return CS_OK;
     if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, crops_kind);
+    const int64_t ch = n < cc ? n : cc;
     const bool host_recon = recon && out_kind == CS_MEM_HOST;
     if ((rc = ensure_workspace(m, ch, host_recon))) return rc;
     for (int64_t off = 0; off < n; off += ch) {
@@ -846,7 +863,8 @@ int cs_encode(cs_model* m, const float* crops, int64_t n, int crops_kind, int wh
     if (!crops || !features) return fail(CS_ERR_INVALID, "crops/features is NULL");
     if (which != 0 && which != 1) return fail(CS_ERR_INVALID, "which must be 0 (autoencoder) or 1 (encoder.keras)");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, crops_kind);
+    const int64_t ch = n < cc ? n : cc;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
     const ConvSet& set = (which == 1 && !m->shared_encoder) ? m->enc : m->ae;
     const size_t fl = m->arch.feat();
@@ -872,7 +890,8 @@ int cs_layer_output(cs_model* m, const float* crops, int64_t n, int crops_kind, 
     const int last = m->arch.n_conv - 1;
     if (layer < 0 || layer > last) return fail(CS_ERR_INVALID, "layer must be in [0,%d]", last);
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, crops_kind);
+    const int64_t ch = n < cc ? n : cc;
     if ((rc = ensure_workspace(m, ch, layer == last))) return rc;
     const size_t fl = m->arch.floats[layer];
     for (int64_t off = 0; off < n; off += ch) {
@@ -897,7 +916,8 @@ int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, fl
     if (!features || !pca_out) return fail(CS_ERR_INVALID, "features/pca_out is NULL");
     if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_scaler_pca needs detector parameters");
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, in_kind);
+    const int64_t ch = n < cc ? n : cc;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
     for (int64_t off = 0; off < n; off += ch) {
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
@@ -922,7 +942,8 @@ int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, doubl
     if (!pca) return fail(CS_ERR_INVALID, "pca is NULL");
     if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_svm_decision needs detector parameters");
-    const int64_t ch = n < m->chunk ? n : m->chunk;
+    const int64_t cc = eff_chunk(m, in_kind);
+    const int64_t ch = n < cc ? n : cc;
     if ((rc = ensure_workspace(m, ch, false))) return rc;
     double* outs[2] = {cons_dec, mod_dec};
     for (int64_t off = 0; off < n; off += ch) {

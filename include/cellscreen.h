@@ -158,7 +158,8 @@ int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights
                          const cs_detector_params *detector, int device_id, cs_model **out);
 void cs_model_free(cs_model *m);
 int cs_model_get_info(const cs_model *m, cs_model_info *info);
-/* Cells per internal pass (workspace ~0.4 MB per cell).  Default 16384. */
+/* Cells per internal pass (workspace ~0.4 MB per cell for the reference graph).  Default: automatic -- 16,384 for
+ * host input (pipelined staging), up to 65,536 for device-resident input (a ~28 GB workspace); this call fixes it. */
 int cs_model_set_chunk(cs_model *m, int64_t chunk_cells);
 
 /* ---- the hot path -------------------------------------------------------------- */

@@ -313,3 +313,23 @@ def test_fused_conv6_conv7_error_matches_the_two_kernel_path(engine, weights):
             ref = orc.cae_forward(weights, x, acc64=True, want=("mse", "mae"))
             assert np.abs(mse_f - ref["mse"]).max() <= 1e-5 * np.abs(ref["mse"]).max()
             assert np.abs(mae_f - ref["mae"]).max() <= 1e-5 * np.abs(ref["mae"]).max()
+
+
+def test_automatic_chunk_by_input_kind(weights, det):
+    """Without cs_model_set_chunk the pass size follows the input: 16,384 cells for host buffers (pipelined staging),
+    as many as a ~28 GB workspace holds (65,536 for the reference graph) for device-resident crops.  Same results."""
+    import torch
+    e = Engine.from_weights(weights, None, det)
+    try:
+        assert e.info.chunk_cells == 65536
+        x = synth.synth_crops(3, 500, 20000)                       # more than one host chunk, less than one device chunk
+        r_host = e.screen(x)
+        r_dev = e.screen(torch.from_numpy(x).cuda())
+        for k in ("mse", "mae", "cons_score", "mod_score", "cons_pred", "mod_pred"):
+            assert np.array_equal(np.asarray(r_host[k]), r_dev[k].cpu().numpy()), k
+        e.set_chunk(4096)
+        assert e.info.chunk_cells == 4096
+        r_small = e.screen(x)
+        assert np.array_equal(r_small["mse"], r_host["mse"]) and np.array_equal(r_small["mod_score"], r_host["mod_score"])
+    finally:
+        e.close()
