@@ -150,12 +150,18 @@ class ImprovedAnomalyDetectionTraining:
         if full is None:
             raise ValueError("pass autoencoder= (the full weight set whose encoder half is `encoder`)")
         e = Engine.from_weights(full, encoder if encoder.n_conv == encoder.n_enc else None, device_id=self.device_id)
-        features_flat = e.encode(np.asarray(cell_images, dtype=np.float32), which=1)    # :401-402
-        e.close()
-        print(f"Flattened features shape: {features_flat.shape}")
+        crops = np.ascontiguousarray(cell_images, dtype=np.float32)
         if self.detector_fit == "device":                                               # :408-444
+            import torch                                   # plumbing: the features stay on the device between encode and fit
+            features_flat = e.encode(torch.from_numpy(crops).cuda(self.device_id), which=1)   # :401-402
+            e.close()
+            print(f"Flattened features shape: {tuple(features_flat.shape)}")
             params, objs = fit_detector_device(features_flat, output_dir=self.output_dir, device_id=self.device_id)
+            del features_flat
         else:
+            features_flat = e.encode(crops, which=1)                                    # :401-402
+            e.close()
+            print(f"Flattened features shape: {features_flat.shape}")
             params, objs = fit_detector(features_flat, output_dir=self.output_dir)
         print(f"PCA reduced to {params.n_components} components")
         print("\nBaseline anomaly rates:")                                              # :430-434
