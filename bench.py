@@ -203,6 +203,21 @@ def main():
                            tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
                            tflops_executed=round(v["flops"] * EXEC_FRACTION.get(k, 1.0) / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None)
                    for k, v in kern.items()}
+        enc_ms = sum(kern[k]["ms"] for k in ("conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool") if k in kern)
+        enc_cells = kern["conv2_relu_bn_pool"]["cells"]
+        enc_hbm = {"algorithmic_bytes_per_cell": 16384 + 8192,
+                   "algorithmic_gbs_at_encoder_rate": round(enc_cells * 24576 / (enc_ms * 1e-3) / 1e9, 1),
+                   "frac_hbm_peak_algorithmic": round(enc_cells * 24576 / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                   "measured_bytes_per_cell": None, "frac_hbm_peak_measured": None, "encoder_ms_per_step": round(enc_ms / args.steps, 3)}
+        try:
+            if traffic_src:
+                tk = json.load(open(os.path.join(ROOT, traffic_src)))["kernels"]
+                mb = sum(tk[k]["hbm_bytes_per_cell"] for k in ("conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool"))
+                enc_hbm["measured_bytes_per_cell"] = round(mb)
+                enc_hbm["frac_hbm_peak_measured"] = round(enc_cells * mb / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                enc_hbm["measured_source"] = traffic_src
+        except Exception:
+            pass
         exec_flop_per_cell = sum(kern[k]["flops"] * EXEC_FRACTION.get(k, 1.0) for k in kern if k.startswith("conv")) / max(
             1, kern["conv2_relu_bn_pool"]["cells"])
         line = {
@@ -224,7 +239,11 @@ def main():
                            "note": "algorithmic = the reference graph's 100.27 MFLOP/cell; executed counts conv2/conv3 (Winograd F(2,3)) and conv7 (folded upsample) at 4/9, conv5/conv6 (folded + Winograd F(2,2)) at 1/4, conv1 at 12/9",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
-                           "device_ms_per_step": round(total_ms / args.steps, 3)},
+                           "device_ms_per_step": round(total_ms / args.steps, 3),
+                           # BASELINE.json asks for the fraction of the HBM roofline on the conv encoder (conv1-3): algorithmic
+                           # bytes = one crop in + 8 KB of features out; measured = PMC traffic of the three kernels (p1 and p2 do
+                           # go through HBM).  Exact-fp32 convs are MFMA-bound, so neither can approach 1.
+                           "conv_encoder_hbm": enc_hbm},
             "roofline": roofline,
             "kernels": kernels,
         }
