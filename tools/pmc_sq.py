@@ -44,6 +44,9 @@ def main():
             cyc = 32 * c["SQ_INSTS_MFMA"] + 4 * (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"])
             c["simd_cycles_mfma_plus_valu"] = cyc
             c["implied_clock_ghz_if_fully_busy"] = round(cyc / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3) / 1e9, 3)
+            # matrix-pipe share of the issue cycles, and matrix-pipe utilisation of the launch at the ~2.1 GHz the chip sustains
+            c["mfma_share_of_issue_cycles"] = round(32 * c["SQ_INSTS_MFMA"] / cyc, 3)
+            c["mfma_util_at_2p1_ghz"] = round(32 * c["SQ_INSTS_MFMA"] / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3 * 2.1e9), 3)
     print(json.dumps({"note": "see tools/pmc_sq.py", "kernels": out}, indent=1))
 
 
