@@ -32,6 +32,8 @@ def crops():
 def test_large_variant_layers_and_reconstruction(large, crops):
     e = Engine.from_weights(large)
     try:
+        # automatic pass size for device-resident input: what a ~28 GB workspace holds (1.9 MB of activations per cell here)
+        assert e.info.chunk_cells == 14336
         assert (e.info.height, e.info.width, e.info.n_conv, e.info.n_enc) == (128, 128, 7, 3)
         assert e.info.reference_arch == 0 and e.info.feature_dim == 16 * 16 * 128
         assert list(e.info.channels[:7]) == list(LARGE_CH)
