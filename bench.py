@@ -13,38 +13,47 @@ N = 1 runs BASELINE.json configs[2] (1M crops on one GPU); N > 1 shards N x 1M c
 contiguous index ranges (weak scaling, no data-path collective before the final gather).
 
 Rank 0 prints ONE JSON line; besides the contract keys it carries
-  roofline      the dominant kernel priced against the exact-fp32 MFMA peak, from HIP events
-                recorded on the library's stream inside the timed steps
-  cpu_baseline  the CPU oracle (oracle/cae_oracle.c, a port of the same path) timed on this
-                host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline      the dominant kernel priced against the exact-fp32 MFMA peak.  `achieved` / `frac`
+                count the matrix-pipe work the kernel EXECUTES (its own MFMA count x 2,048 FLOP, the
+                number SQ_INSTS_MFMA reports) over its launch time from HIP events recorded on the
+                library's stream inside the timed steps -- never above 1; the reference graph's
+                algorithmic FLOPs of the same layers are carried as `achieved_algorithmic` /
+                `algorithmic_speedup` (Winograd and the folded upsample execute fewer multiply-adds).
+                `traffic` = HBM bytes per launch from two rocprofv3 PMC passes (FETCH_SIZE x 2 on
+                gfx950, WRITE_SIZE) of THIS tree: collected by this run in two child processes before
+                the parent touches the GPU, or taken from profiles/*_pmc_traffic.json only when that
+                file carries the hash of the kernel sources of this tree (else null).
+  cpu_baseline  the reference's CPU sequence (improved_detection.py:122-142) on this host's cores:
+                Keras/TF if importable, else its counterpart -- the same graph in torch-CPU at Keras's
+                predict batch of 32, autoencoder pass + separate encoder pass, NumPy MSE/MAE, the real
+                scikit-learn transform / predict / decision_function calls (4 SVM passes) -- on
+                configs[0]'s 128 crops and on 4,096; plus the OpenMP oracle port (rank 0, N = 1 only)
+  train_leg     a short driver-timed run of BASELINE.json configs[1] (CAE training, batch 32)
+  small_n       single-call latency of the hot path from host buffers at N = 128 / 1,024 / 10,240
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "cell-image-analysis_amd"), ROOT):
+for p in (os.path.join(ROOT, "cell-image-analysis_amd"), os.path.join(ROOT, "tools"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0              # spec
 FLOP_PER_CELL = 100_270_080        # ALGORITHMIC: 2 x 50,135,040 conv MACs of the reference graph, SURVEY.md section 8d
-# EXECUTED multiply-adds as a fraction of the algorithmic ones, per kernel (all exact algebra): conv2 and
-# conv3 are Winograd F(2x2,3x3) convolutions (4/9); the convs behind an UpSampling2D are four 2x2-tap phase
-# convs with pre-summed weights (4/9: conv7), conv5 and conv6 additionally as Winograd F(2x2,2x2) per phase
-# (9/16 of 4/9 = 1/4); conv1 pads K = 9 to 12 for the 16x16x4 MFMA.
-EXEC_FRACTION = {"conv1_relu_bn_pool": 12.0 / 9.0,
-                 "conv5_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6") or os.environ.get("CS_NO_WINO5")) else 0.25,
-                 "conv6_up_relu_bn": 4.0 / 9.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO6")) else 0.25,
-                 "conv7_up_sigmoid_err": 4.0 / 9.0,
-                 # conv6 (1/4 of 18,874,368 MACs) and conv7 (4/9 of 1,179,648: channel contraction T = a6 W_eff, then a gather) in one kernel
-                 "conv6_conv7_fused_err": (0.25 * 18874368 + 4.0 / 9.0 * 1179648) / (18874368 + 1179648),
-                 "conv2_relu_bn_pool": 1.0 if os.environ.get("CS_NO_WINOGRAD") else 4.0 / 9.0,
-                 "conv3_relu_bn_pool": 1.0 if (os.environ.get("CS_NO_WINOGRAD") or os.environ.get("CS_NO_WINO3")) else 4.0 / 9.0}
+FLOP_PER_MFMA = 2048               # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
 BYTES_PER_CELL = 16_384 + 18       # algorithmic: read one crop, write 4 fp32/fp64-as-results + 2 int8
+# algorithmic HBM bytes per cell of each kernel family (what it must read + write if nothing is re-read)
+ALG_BYTES = {"conv1_relu_bn_pool": 16384 + 131072, "conv2_relu_bn_pool": 131072 + 65536, "conv3_relu_bn_pool": 65536 + 8192,
+             "conv4_relu_bn": 8192 + 8192, "conv5_up_relu_bn": 8192 + 65536, "conv6_up_relu_bn": 65536 + 131072,
+             "conv7_up_sigmoid_err": 131072 + 16384, "conv6_conv7_fused_err": 65536 + 16384 + 64,
+             "conv1_conv2_fused": 16384 + 65536, "scaler_pca": 8192 + 400}
+ENCODER_KERNELS = ("conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv1_conv2_fused", "conv3_relu_bn_pool")
 
 
 def parse():
@@ -53,19 +62,67 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=1_000_000, help="crops per GPU per step")
-    ap.add_argument("--chunk", type=int, default=65536, help="cells per internal pass (workspace ~0.4 MB per cell)")
+    ap.add_argument("--chunk", type=int, default=65536, help="cells per internal pass (workspace ~0.3 MB per cell)")
     ap.add_argument("--train-cells", type=int, default=5000, help="synthetic crops the detector is fit on")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU baseline (0 = auto, ~15 s)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU port baseline (0 = auto, ~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic with rocprofv3 child passes")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the training leg and the small-N latency leg")
+    ap.add_argument("--train-steps", type=int, default=200)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
 
 
-def cpu_baseline(weights, det, seed, sample):
-    """Times the CPU oracle on a bounded sample of the same synthetic workload."""
-    import numpy as np
+# ------------------------------------------------------------------------------------------- HBM traffic (PMC)
+def collect_pmc_traffic(args):
+    """Two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950) of a 2-launch run of this
+    script, as child processes started BEFORE this process initialises the GPU.  Returns the tools/pmc_traffic.py
+    table or None (rocprofv3 absent / failed: the caller falls back to a hash-matched file in profiles/)."""
+    import shutil
+    import tempfile
+    from pmc_traffic import reduce_passes
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    chunk = 65536
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0", "--cells", str(2 * chunk),
+             "--chunk", str(chunk), "--train-cells", "1000", "--seed", str(args.seed)]
+    try:
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", name, "--output-format", "csv", "-d", os.path.join(base, name), "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=420)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (name, r.returncode, r.stderr.decode(errors="replace")[-300:])
+        return reduce_passes(os.path.join(base, "FETCH_SIZE"), os.path.join(base, "WRITE_SIZE"), chunk), "this run (rocprofv3 child passes)"
+    except Exception as e:  # noqa: BLE001 - any profiler trouble only costs the traffic figure
+        return None, "PMC passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def committed_pmc_traffic():
+    """profiles/*_pmc_traffic.json of THIS tree only: the file must carry the hash of the kernel sources."""
+    from build import source_hash
+    want = source_hash()
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(pdir, f)))
+            except Exception:  # noqa: BLE001
+                continue
+            if tj.get("source_hash") == want:
+                return tj, "profiles/" + f + " (source_hash matches this tree)"
+    return None, "no profiles/*_pmc_traffic.json carries this tree's source_hash " + want[:12]
+
+
+# ------------------------------------------------------------------------------------------- CPU baselines
+def cpu_port(weights, det, seed, sample):
+    """The OpenMP oracle (a port of the same path: shared encoder, one SVM pass) on a bounded sample."""
     from oracle import oracle
-    # use the cores this process may actually run on (the GPU box gives a 1-GPU job a CPU share)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(oracle.num_threads(), avail))
     oracle.set_num_threads(threads)
@@ -74,25 +131,208 @@ def cpu_baseline(weights, det, seed, sample):
     t0 = time.perf_counter()
     oracle.screen(weights, None, det, probe)
     rate = len(probe) / (time.perf_counter() - t0)
-    n = sample if sample > 0 else int(min(65536, max(64, rate * 15)))
+    n = sample if sample > 0 else int(min(65536, max(64, rate * 10)))
     x = oracle.synth_crops(seed, 0, n)
     t0 = time.perf_counter()
     r = oracle.screen(weights, None, det, x)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="cells/s", cores=threads, kind="port", host_cpus_visible=avail,
+    return dict(value=round(n / dt, 1), unit="cells/s", cores=threads, kind="port", host_cpus_visible=avail,
                 sample=f"{n} crops of the same synthetic workload (seed {seed}, cells 0..{n - 1}), "
                        f"oracle/cae_oracle.c fp32 + fp64 SVM, OpenMP {threads} threads, {dt:.1f} s"), r, x
 
 
+def _torch_graph(weights):
+    """The reference graph (CAE_improved_modeltrain.py:191-216) as torch-CPU functional ops, inference mode."""
+    import torch
+    import torch.nn.functional as F
+    ks = [torch.from_numpy(k.transpose(3, 2, 0, 1).copy()) for k in weights.kernels]        # HWIO -> OIHW
+    bs = [torch.from_numpy(b.copy()) for b in weights.biases]
+    bn = [tuple(torch.from_numpy(a.copy()) for a in (weights.bn_mean[l], weights.bn_var[l], weights.bn_gamma[l], weights.bn_beta[l]))
+          for l in range(len(weights.bn_gamma))]
+    n_enc, n_conv, eps = weights.n_enc, weights.n_conv, float(weights.bn_eps)
+
+    def block(h, l):
+        h = F.relu(F.conv2d(h, ks[l], bs[l], padding=1))
+        m, v, g, b = bn[l]
+        return F.batch_norm(h, m, v, g, b, training=False, eps=eps)
+
+    def encoder(x):
+        h = x
+        for l in range(n_enc):
+            h = F.max_pool2d(block(h, l), 2)
+        return h
+
+    def autoencoder(x):
+        h = block(encoder(x), n_enc)
+        for l in range(n_enc + 1, n_conv - 1):
+            h = block(F.interpolate(h, scale_factor=2, mode="nearest"), l)
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+        return torch.sigmoid(F.conv2d(h, ks[-1], bs[-1], padding=1))
+
+    def predict(fn, X):          # Keras Model.predict: batches of 32, outputs concatenated
+        with torch.no_grad():
+            return torch.cat([fn(X[i:i + 32]) for i in range(0, len(X), 32)]).numpy()
+    return autoencoder, encoder, predict
+
+
+def _keras_models(weights):
+    """Only if TensorFlow is importable (not expected in this image): the identical Keras graph with these weights."""
+    import numpy as np
+    import tensorflow as tf  # noqa: F401
+    from tensorflow.keras import layers, models
+    inp = layers.Input(shape=(64, 64, 1))
+    h = inp
+    convs, bns = [], []
+    ch = weights.channels
+    for l in range(weights.n_enc):
+        c = layers.Conv2D(ch[l], (3, 3), activation="relu", padding="same"); h = c(h); convs.append(c)
+        b = layers.BatchNormalization(); h = b(h); bns.append(b)
+        h = layers.MaxPooling2D((2, 2), padding="same")(h)
+    enc_out = h
+    c = layers.Conv2D(ch[weights.n_enc], (3, 3), activation="relu", padding="same"); h = c(h); convs.append(c)
+    b = layers.BatchNormalization(); h = b(h); bns.append(b)
+    for l in range(weights.n_enc + 1, weights.n_conv - 1):
+        h = layers.UpSampling2D((2, 2))(h)
+        c = layers.Conv2D(ch[l], (3, 3), activation="relu", padding="same"); h = c(h); convs.append(c)
+        b = layers.BatchNormalization(); h = b(h); bns.append(b)
+    h = layers.UpSampling2D((2, 2))(h)
+    c = layers.Conv2D(1, (3, 3), activation="sigmoid", padding="same"); h = c(h); convs.append(c)
+    ae, en = models.Model(inp, h), models.Model(inp, enc_out)
+    for l, c in enumerate(convs):
+        c.set_weights([weights.kernels[l], weights.biases[l]])
+    for l, b in enumerate(bns):
+        b.set_weights([weights.bn_gamma[l], weights.bn_beta[l], weights.bn_mean[l], weights.bn_var[l]])
+    return (lambda X: ae.predict(X, verbose=0)), (lambda X: en.predict(X, verbose=0)), np
+
+
+def cpu_reference_sequence(weights, sk, seed, sizes=(128, 4096)):
+    """improved_detection.py:122-142 literally, on the host: X -> autoencoder.predict -> MSE/MAE -> encoder.predict ->
+    flatten -> scaler.transform -> pca.transform -> 2x predict + 2x decision_function.  sk = the fitted scikit-learn
+    objects.  Keras/TF when importable ("reference"), else torch-CPU for the two predict calls ("counterpart")."""
+    import numpy as np
+    import torch
+    from cellscreen import synth
+    kind, label = "counterpart", "torch-CPU + sklearn counterpart of the reference CPU path"
+    try:
+        ae_predict, en_predict, _ = _keras_models(weights)
+        kind, label = "reference", "Keras/TF-CPU, reference sequence"
+        to_in = lambda X: X                                                              # noqa: E731
+    except Exception:  # noqa: BLE001 - TensorFlow absent (the expected case) or unusable
+        ae, en, predict = _torch_graph(weights)
+        ae_predict = lambda X: predict(ae, X).transpose(0, 2, 3, 1)                      # noqa: E731
+        en_predict = lambda X: predict(en, X).transpose(0, 2, 3, 1)                      # noqa: E731
+        to_in = lambda X: torch.from_numpy(np.ascontiguousarray(X.transpose(0, 3, 1, 2)))  # noqa: E731
+    scaler, pca, dets = sk["scaler"], sk["pca"], sk["detectors"]
+    out = {}
+    last = None
+    for n in sizes:
+        cells = list(synth.synth_crops(seed, 0, n))
+        best = None
+        for rep in range(2 if n <= 512 else 1):                   # the small case twice: the first call pays one-time set-up
+            t0 = time.perf_counter()
+            X = np.expand_dims(np.array(cells), axis=-1).astype("float32")                  # :122
+            Xin = to_in(X)
+            rec = ae_predict(Xin)                                                          # :125
+            mse = np.mean(np.square(X - rec), axis=(1, 2, 3))                               # :126
+            mae = np.mean(np.abs(X - rec), axis=(1, 2, 3))                                  # :127
+            t1 = time.perf_counter()
+            enc = en_predict(Xin)                                                          # :130
+            flat = np.ascontiguousarray(enc).reshape(len(enc), -1)                          # :131
+            t2 = time.perf_counter()
+            red = pca.transform(scaler.transform(flat))                                     # :134-135
+            t3 = time.perf_counter()
+            cp = dets["Conservative"].predict(red); mp = dets["Moderate"].predict(red)      # :138-139
+            cs = dets["Conservative"].decision_function(red); ms = dets["Moderate"].decision_function(red)   # :141-142
+            t4 = time.perf_counter()
+            rec_ = dict(cells_per_s=round(n / (t4 - t0), 1), wall_ms=round((t4 - t0) * 1e3, 2),
+                        split_ms=dict(autoencoder_predict_and_errors=round((t1 - t0) * 1e3, 2), encoder_predict=round((t2 - t1) * 1e3, 2),
+                                      scaler_pca=round((t3 - t2) * 1e3, 2), svm_4_calls=round((t4 - t3) * 1e3, 2)))
+            if best is None or rec_["wall_ms"] < best["wall_ms"]:
+                best = rec_
+            last = dict(mse=mse, mae=mae, cons_score=-cs, mod_score=-ms, cons_pred=cp, mod_pred=mp)
+        out[str(n)] = best
+    big = out[str(sizes[-1])]
+    return dict(value=big["cells_per_s"], unit="cells/s", cores=torch.get_num_threads(), kind=kind, label=label,
+                sample="%d crops (seed %d); also BASELINE.json configs[0]'s 128 crops: %.1f cells/s" % (sizes[-1], seed, out[str(sizes[0])]["cells_per_s"]),
+                sizes=out, host_cpu_count=os.cpu_count(), torch_threads=torch.get_num_threads(),
+                omp_num_threads=os.environ.get("OMP_NUM_THREADS"), cpu_model=_cpu_model()), last
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+# ------------------------------------------------------------------------------------------- extra legs
+def train_leg(steps, local_rank, seed):
+    """BASELINE.json configs[1]: CAE training, batch 32, crops resident in HBM; `steps` timed fit() batches."""
+    import torch
+    from cellscreen import synth
+    from cellscreen.trainer import Trainer
+    dev = torch.device("cuda", local_rank)
+    X = torch.from_numpy(synth.blob_crops(seed, 4096)).to(dev)
+    tr = Trainer(synth.random_cae(seed=seed, trivial_bn=True), device_id=local_rank)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234)
+    idx = torch.randint(0, len(X), (steps + 20, 32), device=dev, generator=gen)
+    first = last = None
+    try:
+        for i in range(20):
+            xb = X[idx[i]].contiguous(); torch.cuda.current_stream().synchronize()
+            l, _ = tr.step(xb, xb, 1e-3)
+            first = l if first is None else first
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20, steps + 20):
+            xb = X[idx[i]].contiguous(); torch.cuda.current_stream().synchronize()
+            last, _ = tr.step(xb, xb, 1e-3)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        tr.close()
+    return dict(workload="BASELINE.json configs[1]: CAE training (fwd + bwd + Adam, BN batch statistics), batch 32, fp32, 1 GPU",
+                steps=steps, ms_per_step=round(el / steps * 1e3, 4), cells_per_s=round(steps * 32 / el, 1),
+                tflops_algorithmic=round(steps * 32 / el * 3 * FLOP_PER_CELL / 1e12, 3),
+                epoch_seconds_at_1250_steps=round(el / steps * 1250, 3), loss_first_last=[round(first, 6), round(last, 6)])
+
+
+def small_n_leg(eng, seed):
+    """The reference calls the hot path once per sample with 1e2..1e4 cells in host memory (improved_detection.py:199):
+    single-call wall time of cs_screen from numpy crops to numpy results."""
+    import numpy as np
+    from cellscreen import synth
+    out = {}
+    for n in (128, 1024, 10240):
+        x = synth.synth_crops(seed, 5_000_000, n)
+        eng.screen(x)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            eng.screen(x)
+            ts.append(time.perf_counter() - t0)
+        out[str(n)] = dict(ms=round(float(np.median(ts)) * 1e3, 3), cells_per_s=round(n / float(np.median(ts)), 1))
+    return out
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- HBM traffic of this tree: PMC child passes first, while this process has not touched the GPU yet
+    pmc, pmc_src = None, None
+    if world == 1 and not args.pmc_child and not args.no_pmc:
+        pmc, pmc_src = collect_pmc_traffic(args)
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -114,10 +354,11 @@ def main():
     enc = Engine.from_weights(weights, device_id=local_rank)
     xt = torch.empty((args.train_cells, 64, 64), dtype=torch.float32, device=dev)
     enc.synth_crops(args.seed, 10_000_000_000, xt)               # disjoint from the screened cells
+    torch.cuda.current_stream().synchronize()
     feats = enc.encode(xt, which=0).cpu().numpy()
     enc.close()
     del xt
-    det, _ = fit_detector(feats, pca_random_state=0)             # same on every rank (same inputs)
+    det, sk = fit_detector(feats, pca_random_state=0)            # same on every rank (same inputs)
     eng = Engine.from_weights(weights, None, det, device_id=local_rank)
     eng.set_chunk(args.chunk)
 
@@ -130,6 +371,7 @@ def main():
     out = dict(mse=torch.empty(n_local, dtype=torch.float32, device=dev), mae=torch.empty(n_local, dtype=torch.float32, device=dev),
                cons_score=torch.empty(n_local, dtype=torch.float64, device=dev), mod_score=torch.empty(n_local, dtype=torch.float64, device=dev),
                cons_pred=torch.empty(n_local, dtype=torch.int8, device=dev), mod_pred=torch.empty(n_local, dtype=torch.int8, device=dev))
+    torch.cuda.synchronize()
 
     # the 18 B/cell of results end on rank 0's host: pinned destination buffers, one async copy per field
     host = {k: torch.empty(n_total, dtype=v.dtype, pin_memory=True) for k, v in out.items()} if rank == 0 else None
@@ -168,58 +410,67 @@ def main():
     prof = eng.profile()
     if rank == 0:
         value = n_total * args.steps / elapsed
-        # ---- roofline: dominant kernel by device time, algorithmic FLOPs / measured duration
         kern = {k: v for k, v in prof.items() if v["launches"] > 0}
         total_ms = sum(v["ms"] for v in kern.values())
-        dom = max((k for k in kern if kern[k]["flops"] > 0), key=lambda k: kern[k]["ms"])
+        ex_tf = lambda v: v["mfma_per_cell"] * FLOP_PER_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12      # noqa: E731
+        # ---- roofline: dominant kernel by device time, EXECUTED matrix-pipe FLOPs / measured duration
+        dom = max((k for k in kern if kern[k]["mfma_per_cell"] > 0), key=lambda k: kern[k]["ms"])
         d = kern[dom]
         avg_ms = d["ms"] / d["launches"]
-        ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
-        # HBM traffic of that kernel: measured with rocprofv3 PMC passes (tools/pmc_traffic.py; a profiler
-        # cannot run inside this process), bytes per cell x the cells this launch processed
-        traffic, traffic_src = None, None
+        cpl = d["cells"] / d["launches"]
+        ach = ex_tf(d)
+        alg = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        if pmc is None and not args.pmc_child:
+            pmc, pmc_src = committed_pmc_traffic()
+        tk = pmc["kernels"] if pmc else {}
+        traffic = round(tk[dom]["hbm_bytes_per_cell"] * cpl) if dom in tk else None
+        # cross-check of the MFMA count against SQ_INSTS_MFMA when a counters file of this tree is committed
+        sq_check = None
         try:
-            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            if pmc:
-                tj = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
-                if dom in tj["kernels"]:
-                    traffic = round(tj["kernels"][dom]["hbm_bytes_per_cell"] * (d["cells"] / d["launches"]))
-                    traffic_src = "profiles/" + pmc[-1]
-        except Exception:
+            from build import source_hash
+            for f in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if f.endswith("_sq_counters.json"):
+                    sj = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    if sj.get("source_hash") == source_hash() and dom in sj["kernels"] and "SQ_INSTS_MFMA" in sj["kernels"][dom]:
+                        per_cell = sj["kernels"][dom]["SQ_INSTS_MFMA"] / sj.get("cells_per_launch", 65536)
+                        sq_check = dict(file="profiles/" + f, sq_insts_mfma_per_cell=round(per_cell, 2),
+                                        library_mfma_per_cell=d["mfma_per_cell"], equal=bool(abs(per_cell - d["mfma_per_cell"]) < 0.5))
+                    break
+        except Exception:  # noqa: BLE001
             pass
         roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        achieved_executed=round(ach * EXEC_FRACTION.get(dom, 1.0), 3),
-                        frac_executed=round(ach * EXEC_FRACTION.get(dom, 1.0) / FP32_MFMA_PEAK_TFLOPS, 4),
-                        note=("achieved counts the reference graph's algorithmic FLOPs of this layer; the kernel executes "
-                              "%.3f of them (Winograd / folded upsample), which is why frac can exceed 1" % EXEC_FRACTION.get(dom, 1.0))
-                        if EXEC_FRACTION.get(dom, 1.0) != 1.0 else None,
-                        traffic=traffic, traffic_unit="HBM bytes per launch",
-                        traffic_source=traffic_src,
-                        algorithmic_bytes_per_launch=int((131072 + 65536) * (d["cells"] / d["launches"])) if dom.startswith("conv2") else None,
-                        avg_launch_ms=round(avg_ms, 4), cells_per_launch=d["cells"] // d["launches"],
+                        executed_mfma_per_cell=d["mfma_per_cell"], executed_flop_per_launch=int(d["mfma_per_cell"] * FLOP_PER_MFMA * cpl),
+                        achieved_algorithmic=round(alg, 3), algorithmic_speedup=round(alg / ach, 4) if ach > 0 else None,
+                        note="achieved/frac price the multiply-adds the kernel executes (its MFMA count x 2,048 FLOP); achieved_algorithmic "
+                             "counts the reference graph's FLOPs of the same layers, of which Winograd / folded-upsample kernels execute a fraction",
+                        sq_insts_mfma_check=sq_check,
+                        traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=pmc_src,
+                        algorithmic_bytes_per_launch=int(ALG_BYTES[dom] * cpl) if dom in ALG_BYTES else None,
+                        avg_launch_ms=round(avg_ms, 4), cells_per_launch=int(cpl),
                         share_of_device_time=round(d["ms"] / total_ms, 4))
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], share=round(v["ms"] / total_ms, 4),
-                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
-                           tflops_executed=round(v["flops"] * EXEC_FRACTION.get(k, 1.0) / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None)
+                           tflops_executed=round(ex_tf(v), 2) if v["mfma_per_cell"] > 0 else None,
+                           frac_executed=round(ex_tf(v) / FP32_MFMA_PEAK_TFLOPS, 4) if v["mfma_per_cell"] > 0 else None,
+                           tflops_algorithmic=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
+                           hbm_bytes_per_cell=tk[k]["hbm_bytes_per_cell"] if k in tk else None,
+                           algorithmic_bytes_per_cell=ALG_BYTES.get(k))
                    for k, v in kern.items()}
-        enc_ms = sum(kern[k]["ms"] for k in ("conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool") if k in kern)
-        enc_cells = kern["conv2_relu_bn_pool"]["cells"]
-        enc_hbm = {"algorithmic_bytes_per_cell": 16384 + 8192,
+        enc_k = [k for k in ENCODER_KERNELS if k in kern]
+        enc_ms = sum(kern[k]["ms"] for k in enc_k)
+        enc_cells = kern[enc_k[0]]["cells"]
+        enc_hbm = {"kernels": enc_k, "algorithmic_bytes_per_cell": 16384 + 8192,
                    "algorithmic_gbs_at_encoder_rate": round(enc_cells * 24576 / (enc_ms * 1e-3) / 1e9, 1),
                    "frac_hbm_peak_algorithmic": round(enc_cells * 24576 / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                    "measured_bytes_per_cell": None, "frac_hbm_peak_measured": None, "encoder_ms_per_step": round(enc_ms / args.steps, 3)}
-        try:
-            if traffic_src:
-                tk = json.load(open(os.path.join(ROOT, traffic_src)))["kernels"]
-                mb = sum(tk[k]["hbm_bytes_per_cell"] for k in ("conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool"))
-                enc_hbm["measured_bytes_per_cell"] = round(mb)
-                enc_hbm["frac_hbm_peak_measured"] = round(enc_cells * mb / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                enc_hbm["measured_source"] = traffic_src
-        except Exception:
-            pass
-        exec_flop_per_cell = sum(kern[k]["flops"] * EXEC_FRACTION.get(k, 1.0) for k in kern if k.startswith("conv")) / max(
-            1, kern["conv2_relu_bn_pool"]["cells"])
+        if tk and all(k in tk for k in enc_k):
+            mb = sum(tk[k]["hbm_bytes_per_cell"] for k in enc_k)
+            enc_hbm["measured_bytes_per_cell"] = round(mb)
+            enc_hbm["frac_hbm_peak_measured"] = round(enc_cells * mb / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            enc_hbm["measured_source"] = pmc_src
+        conv_cells = max(kern[k]["cells"] for k in kern if k.startswith("conv"))
+        exec_flop_per_cell = sum(kern[k]["mfma_per_cell"] * FLOP_PER_MFMA * kern[k]["cells"] for k in kern if k.startswith("conv")) / max(1, conv_cells)
+        whole_traffic = round(sum(tk[k]["hbm_bytes_per_cell"] for k in kern if k in tk)) if tk else None
         line = {
             "metric": "cells/sec screened (CAE fwd + recon-MSE + SVM score), 64x64",
             "value": round(value, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,25 +483,30 @@ def main():
                        "n_sv": [int(det.conservative.n_sv), int(det.moderate.n_sv)], "detector_train_cells": args.train_cells,
                        "weights": "random init (Glorot, non-trivial BN), seed %d" % args.seed,
                        "parallelism": "dp%d" % world},
-            "whole_path": {"tflops_algorithmic": round(value * FLOP_PER_CELL / 1e12 / world, 3),
-                           "frac_fp32_mfma_peak": round(value * FLOP_PER_CELL / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "tflops_executed": round(value * exec_flop_per_cell / 1e12 / world, 3),
-                           "frac_fp32_mfma_peak_executed": round(value * exec_flop_per_cell / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "note": "algorithmic = the reference graph's 100.27 MFLOP/cell; executed counts conv2/conv3 (Winograd F(2,3)) and conv7 (folded upsample) at 4/9, conv5/conv6 (folded + Winograd F(2,2)) at 1/4, conv1 at 12/9",
+            "whole_path": {"tflops_executed": round(value * exec_flop_per_cell / 1e12 / world, 3),
+                           "frac_fp32_mfma_peak": round(value * exec_flop_per_cell / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "executed_flop_per_cell": int(exec_flop_per_cell),
+                           "tflops_algorithmic": round(value * FLOP_PER_CELL / 1e12 / world, 3),
+                           "algorithmic_speedup": round(FLOP_PER_CELL / exec_flop_per_cell, 4),
+                           "note": "executed = sum of the conv kernels' MFMA counts x 2,048 FLOP per cell; algorithmic = the reference graph's 100.27 MFLOP/cell",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
+                           "hbm_bytes_per_cell_measured": whole_traffic,
+                           "hbm_gbs_measured": round(value * whole_traffic / 1e9 / world, 1) if whole_traffic else None,
                            "device_ms_per_step": round(total_ms / args.steps, 3),
                            # BASELINE.json asks for the fraction of the HBM roofline on the conv encoder (conv1-3): algorithmic
-                           # bytes = one crop in + 8 KB of features out; measured = PMC traffic of the three kernels (p1 and p2 do
-                           # go through HBM).  Exact-fp32 convs are MFMA-bound, so neither can approach 1.
+                           # bytes = one crop in + 8 KB of features out; measured = PMC traffic of its kernels.  Exact-fp32
+                           # convs are MFMA-bound, so neither can approach 1.
                            "conv_encoder_hbm": enc_hbm},
             "roofline": roofline,
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cb, ref, xs = cpu_baseline(weights, det, args.seed, args.cpu_sample)
+        if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
+            cb, ref_seq = cpu_reference_sequence(weights, sk, args.seed)
+            port, ref, xs = cpu_port(weights, det, args.seed, args.cpu_sample)
+            cb["port"] = port
             line["cpu_baseline"] = cb
-            # the bounded sample doubles as a live parity check of the benchmarked run
+            # the bounded samples double as live parity checks of the benchmarked run
             n = len(xs)
             mse = res["mse"][:n].numpy()
             rel = float(np.max(np.abs(mse - ref["mse"]) / ref["mse"]))
@@ -258,6 +514,23 @@ def main():
             derr = float(np.max(np.abs(res["cons_score"][:n].numpy() - ref["cons_score"])))
             line["parity_on_cpu_sample"] = {"cells": n, "mse_max_rel": rel, "cons_score_max_abs": derr,
                                             "ok": bool(rel <= 1e-5 and derr <= tol)}
+            m = len(ref_seq["mse"])       # the reference sequence itself (fp32 library arithmetic): looser by its own rounding
+            rel2 = float(np.max(np.abs(res["mse"][:m].numpy() - ref_seq["mse"]) / ref_seq["mse"]))
+            derr2 = float(np.max(np.abs(res["cons_score"][:m].numpy() - ref_seq["cons_score"])))
+            sure = np.abs(ref_seq["cons_score"]) > tol
+            line["parity_vs_reference_sequence"] = {"cells": m, "mse_max_rel": rel2, "cons_score_max_abs": derr2, "score_tol": tol,
+                                                    "labels_equal_away_from_0": bool(np.array_equal(res["cons_pred"][:m].numpy()[sure], ref_seq["cons_pred"][sure]))}
+        if world == 1 and not args.no_extra_legs and not args.pmc_child:
+            try:
+                line["small_n"] = small_n_leg(eng, args.seed)
+            except Exception as e:  # noqa: BLE001 - an extra leg never costs the headline line
+                line["small_n"] = {"error": repr(e)}
+            del x
+            torch.cuda.empty_cache()
+            try:
+                line["train_leg"] = train_leg(args.train_steps, local_rank, args.seed)
+            except Exception as e:  # noqa: BLE001
+                line["train_leg"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

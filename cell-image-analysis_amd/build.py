@@ -12,11 +12,23 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcellscreen.so")
 BUILD = os.path.join(HERE, "build")
 SOURCES = ["api.hip", "conv_mfma.hip", "conv_out.hip", "detector.hip", "train.hip", "train_api.hip", "preprocess.hip",
-           "conv_wino_cs.hip", "conv_generic.hip", "conv_wino_up.hip", "fit.hip"]
+           "conv_wino_cs.hip", "conv12_fused.hip", "conv_generic.hip", "conv_wino_up.hip", "fit.hip"]
 HEADERS = ["common.hpp", "api_internal.hpp", "tensor_archive.hpp", os.path.join("..", "..", "include", "cellscreen.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]
+
+
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp and the C-ABI header): names a tree's kernels without git (the
+    GPU box gets a snapshot without .git).  Measurement files under profiles/ carry it; bench.py refuses a PMC table
+    whose hash is not this tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
 
 
 def _newer(target, deps):

@@ -198,5 +198,8 @@ class Engine:
         for k in range(self._lib.cs_profile_kernel_count()):
             ms, ln, cells, fl = C.c_double(), C.c_int64(), C.c_int64(), C.c_double()
             L.check(self._lib.cs_profile_get(self._h, k, C.byref(ms), C.byref(ln), C.byref(cells), C.byref(fl)))
-            out[self._lib.cs_profile_kernel_name(k).decode()] = dict(ms=ms.value, launches=ln.value, cells=cells.value, flops=fl.value)
+            mf = C.c_double()
+            L.check(self._lib.cs_profile_mfma_per_cell(self._h, k, C.byref(mf)))
+            out[self._lib.cs_profile_kernel_name(k).decode()] = dict(ms=ms.value, launches=ln.value, cells=cells.value, flops=fl.value,
+                                                                      mfma_per_cell=mf.value)
         return out

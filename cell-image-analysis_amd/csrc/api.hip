@@ -27,10 +27,12 @@ const char* last_error_cstr() { return g_err.c_str(); }
 static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool",
                                             "conv4_relu_bn",      "conv5_up_relu_bn",   "conv6_up_relu_bn",
                                             "conv7_up_sigmoid_err", "scaler_pca",       "ocsvm_decision",
-                                            "finalize",           "synth_crops",        "conv6_conv7_fused_err"};
+                                            "finalize",           "synth_crops",        "conv6_conv7_fused_err",
+                                            "conv1_conv2_fused"};
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
+    DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
     DevBuf ep[6];          // [3][cout] bias, bn_scale, bn_shift
@@ -67,6 +69,7 @@ struct cs_model {
     bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
     bool wino6 = getenv("CS_NO_WINO6") == nullptr;         // A/B knob: conv5/conv6 folded-direct instead of F(2x2,2x2) phases
     bool wino5 = getenv("CS_NO_WINO5") == nullptr;         // A/B knob: conv5 only
+    bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
@@ -228,6 +231,12 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             tmp.resize(pack_wino_cs_fragments(l, nullptr, nullptr));
             pack_wino_cs_fragments(l, w->kernel[l], tmp.data());
             rc = upload(set.winocs[l], tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+        }
+        if (l == 1) {
+            tmp.resize(pack_conv12_fragments(nullptr, nullptr));
+            pack_conv12_fragments(w->kernel[l], tmp.data());
+            rc = upload(set.c12, tmp.data(), tmp.size() * sizeof(float));
             if (rc) return rc;
         }
     }
@@ -410,7 +419,13 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     if (!m->arch.ref) return run_convs_generic(m, &set == &m->enc ? m->genc : m->gae, x, nc, first, last, recon);
     // screening needs neither a6 nor the reconstruction: conv6, conv7 and the error sums run as one kernel
     const bool fused = m->fuse67 && m->use_wino && m->wino6 && first <= 5 && last >= 6 && !recon;
-    for (int l = first; l <= last && l < (fused ? 5 : 6); ++l) {
+    // conv1 + conv2 as one kernel whenever p1 itself is not asked for (it is never written then)
+    const bool fused12 = m->fuse12 && m->use_wino && first == 0 && last >= 1;
+    if (fused12)
+        LAUNCH(K_CONV12_FUSED, nc,
+               launch_conv12_fused(x, set.wfrag[0].as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
+                                   m->act[1].as<float>(), nc, m->stream));
+    for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
             LAUNCH(K_CONV1 + l, nc,
@@ -1003,10 +1018,45 @@ int cs_profile_get(cs_model* m, int k, double* total_ms, int64_t* launches, int6
         double per_cell = 0.0;
         if (k <= K_CONV7_ERR) per_cell = 2.0 * kLayerMacs[k];
         else if (k == K_CONV67_FUSED) per_cell = 2.0 * (kLayerMacs[5] + kLayerMacs[6]);
+        else if (k == K_CONV12_FUSED) per_cell = 2.0 * (kLayerMacs[0] + kLayerMacs[1]);
         else if (k == K_SCALER_PCA) per_cell = 2.0 * (double)m->F * m->C;
         else if (k == K_SVM) per_cell = 0.0;  // fp64, reported separately
         *flops = per_cell * (double)m->prof_cells[k];
     }
+    return CS_OK;
+}
+
+// Matrix-pipe instructions (v_mfma_f32_16x16x4_f32 = 1,024 multiply-adds each) one cell costs in kernel family k with
+// the kernels this handle actually runs -- the EXECUTED work behind a roofline fraction (Winograd and the folded
+// upsample execute fewer multiply-adds than the layer's algorithmic count; conv1 pads K = 9 to 12).  The same
+// number is what SQ_INSTS_MFMA counts per cell (profiles/*_sq_counters.json).  0 for kernels without MFMAs
+// (and for the fp64 SVM, which is priced separately).
+int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
+{
+    if (!m || !mfma || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
+    double v = 0.0;
+    if (m->arch.ref) {
+        const bool wn = m->use_wino;
+        switch (k) {
+            case K_CONV1: v = 1536; break;                                  // 256 tiles x 2 slices x 3 K steps
+            case K_CONV2: v = wn ? 8192 : 18432; break;                     // F(2x2,3x3): 16 points x 16 groups x 8 x 4
+            case K_CONV3: v = (wn && m->wino3) ? 2048 : 4608; break;
+            case K_CONV4: v = 576; break;
+            case K_CONV5: v = (wn && m->wino6 && m->wino5) ? 1152 : 2048; break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
+            case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
+            case K_CONV67_FUSED: v = 4608 + 512; break;                     // conv6 phases + conv7's 32 -> 16 contraction
+            case K_CONV12_FUSED: v = 4608 + 1536; break;                    // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct
+            case K_SCALER_PCA: v = (double)m->fpad * m->cpad / 1024.0; break;
+            default: v = 0.0;
+        }
+    } else if (k <= K_CONV6 || k == K_CONV7_ERR) {
+        const int l = k == K_CONV7_ERR ? m->arch.n_conv - 1 : k - K_CONV1;
+        if (l < m->arch.n_conv) {
+            const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
+            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * (9.0 * m->arch.cin(l) / 4.0);
+        }
+    }
+    *mfma = v;
     return CS_OK;
 }
 

@@ -271,6 +271,10 @@ const char *cs_profile_kernel_name(int kernel_id);
  * flops: algorithmic FLOPs of those launches (2 x MACs of the reference graph). */
 int cs_profile_get(cs_model *m, int kernel_id, double *total_ms, int64_t *launches,
                    int64_t *cells, double *flops);
+/* Matrix-pipe instructions (v_mfma_f32_16x16x4_f32, 2,048 FLOP each) one cell costs in that kernel family with
+ * the kernels this handle runs: the EXECUTED work a roofline fraction is priced with (Winograd / folded-upsample
+ * kernels execute fewer multiply-adds than the layer's algorithmic count).  Equals SQ_INSTS_MFMA per cell. */
+int cs_profile_mfma_per_cell(cs_model *m, int kernel_id, double *mfma);
 
 /* ---- training ---------------------------------------------------------------------- */
 typedef struct cs_trainer cs_trainer;

@@ -333,3 +333,41 @@ def test_automatic_chunk_by_input_kind(weights, det):
         assert np.array_equal(r_small["mse"], r_host["mse"]) and np.array_equal(r_small["mod_score"], r_host["mod_score"])
     finally:
         e.close()
+
+
+def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
+    """conv1 + conv2 run as ONE kernel (conv12_fused.hip: conv2 as Winograd F(4x4,3x3), p1 rows produced into an LDS ring and
+    never written to HBM) whenever p1 itself is not asked for.  Every element of p2 -- 600 cells = more than two cells per
+    persistent workgroup (256 CUs x 1), so the ring wrap between cells, the crop prefetch and every workgroup are
+    covered -- against the fp64-evaluated oracle at the layer bar, and against the two-kernel path (CS_NO_FUSE12=1:
+    conv1 kernel -> p1 in HBM -> F(2x2,3x3) conv2).  p1 of the stand-alone conv1 kernel (what layer_output(0) and
+    training use) gets the same full-coverage compare: 600 cells = 2,400 strips > 2 x its 1,024 resident workgroups."""
+    n = 600
+    x = synth.synth_crops(11, 7000, n)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, ::2] = 0.0                                        # row stripes: every row of the ring matters
+    x[3, :, ::2] = 0.0                                     # column stripes: halo columns / patch columns
+    x[4:40] = synth.blob_crops(5, 36)
+    ref = oracle.cae_forward(weights, x, acc64=True, want=("features",), layers=True)["layers"]
+    e = Engine.from_weights(weights)
+    os.environ["CS_NO_FUSE12"] = "1"
+    try:
+        e2 = Engine.from_weights(weights)
+    finally:
+        del os.environ["CS_NO_FUSE12"]
+    try:
+        p1 = e.layer_output(x, 0)
+        p2 = e.layer_output(x, 1)
+        p2_two = e2.layer_output(x, 1)
+    finally:
+        e.close(); e2.close()
+    s1, s2 = np.abs(ref[0]).max(), np.abs(ref[1]).max()
+    e1 = np.abs(p1.astype(np.float64) - ref[0]).max(axis=(1, 2, 3)) / s1
+    ef = np.abs(p2.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
+    et = np.abs(p2_two.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
+    print("p1 max err / range %.2e; p2 fused %.2e (worst cell %d), two-kernel %.2e" % (e1.max(), ef.max(), int(ef.argmax()), et.max()))
+    assert e1.max() <= 1e-5, f"conv1: cell {int(e1.argmax())}"
+    assert et.max() <= 1e-5
+    assert ef.max() <= 1e-5, f"fused conv1+conv2: cell {int(ef.argmax())} off by {ef.max():.3e} of the range"
+    assert not np.array_equal(p2, p2_two), "the knob did not select a different kernel"

@@ -47,7 +47,8 @@ def main():
             # matrix-pipe share of the issue cycles, and matrix-pipe utilisation of the launch at the ~2.1 GHz the chip sustains
             c["mfma_share_of_issue_cycles"] = round(32 * c["SQ_INSTS_MFMA"] / cyc, 3)
             c["mfma_util_at_2p1_ghz"] = round(32 * c["SQ_INSTS_MFMA"] / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3 * 2.1e9), 3)
-    print(json.dumps({"note": "see tools/pmc_sq.py", "kernels": out}, indent=1))
+    from build import source_hash
+    print(json.dumps({"note": "see tools/pmc_sq.py", "source_hash": source_hash(), "cells_per_launch": 65536, "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":

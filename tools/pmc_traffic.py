@@ -18,7 +18,10 @@ import os
 import json
 import sys
 
-KERNELS = [("ConvCfg<64, 64, 1, 32, 1", "conv1_relu_bn_pool"), ("ConvCfg<32, 32, 32, 64, 1", "conv2_relu_bn_pool"),
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cell-image-analysis_amd"))
+
+KERNELS = [("conv12_fused_kernel", "conv1_conv2_fused"), ("ConvCfg<64, 64, 1, 32, 1", "conv1_relu_bn_pool"), ("ConvCfg<32, 32, 32, 64, 1", "conv2_relu_bn_pool"),
            ("conv2_wino_ring_kernel", "conv2_relu_bn_pool"), ("WinoCfg<32, 32, 32, 64>", "conv2_relu_bn_pool"), ("WinoCfg<16, 16, 64, 32>", "conv3_relu_bn_pool"),
            ("ConvCfg<16, 16, 64, 32, 1", "conv3_relu_bn_pool"), ("ConvCfg<8, 8, 32, 32, 0", "conv4_relu_bn"),
            ("ConvCfg<16, 16, 32, 64, 0", "conv5_up_relu_bn"), ("ConvCfg<32, 32, 64, 32, 0", "conv6_up_relu_bn"),
@@ -44,18 +47,25 @@ def per_kernel(d, counter, chunk):
     return out
 
 
-def main():
-    fetch_dir, write_dir, chunk = sys.argv[1], sys.argv[2], int(sys.argv[3])
+def reduce_passes(fetch_dir, write_dir, chunk):
+    """The two PMC passes -> {"kernels": {family: bytes per cell}}; stamped with the hash of the kernel sources so that
+    bench.py can tell a table of this tree from a stale one."""
+    from build import source_hash
     f = per_kernel(fetch_dir, "FETCH_SIZE", chunk)
     w = per_kernel(write_dir, "WRITE_SIZE", chunk)
-    res = {"cells_per_launch": chunk, "note": "HBM bytes per cell = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / cells_per_launch", "kernels": {}}
+    res = {"cells_per_launch": chunk, "source_hash": source_hash(),
+           "note": "HBM bytes per cell = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / cells_per_launch", "kernels": {}}
     for _, name in KERNELS:
         if name in f and name in w:
             rd = 2.0 * f[name]["kib_per_launch"] * 1024 / chunk
             wr = w[name]["kib_per_launch"] * 1024 / chunk
             res["kernels"][name] = dict(read_bytes_per_cell=round(rd, 1), write_bytes_per_cell=round(wr, 1),
                                         hbm_bytes_per_cell=round(rd + wr, 1), avg_launch_ms_under_pmc=round(f[name]["avg_ms"], 4))
-    print(json.dumps(res, indent=1))
+    return res
+
+
+def main():
+    print(json.dumps(reduce_passes(sys.argv[1], sys.argv[2], int(sys.argv[3])), indent=1))
 
 
 if __name__ == "__main__":
