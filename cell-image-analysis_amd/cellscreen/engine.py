@@ -81,6 +81,10 @@ class Engine:
 
     @classmethod
     def from_model_dir(cls, model_dir: str, device_id: int = 0) -> "Engine":
+        """model_dir: the native file set, or the reference's six files (improved_detection.py:28-41: two `.keras`
+        archives + four pickles), which are converted on the spot."""
+        from . import model_io
+        model_dir = model_io.ensure_native_model_dir(model_dir)
         lib = L.load_library()
         h = C.c_void_p()
         L.check(lib.cs_model_load(model_dir.encode(), device_id, C.byref(h)))

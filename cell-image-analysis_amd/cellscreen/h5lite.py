@@ -248,3 +248,151 @@ def read(src) -> Dict[str, np.ndarray]:
 
     walk(f.root, "", 0)
     return out
+
+
+# =================================================================================================
+# Writer: the same subset, in the "earliest" layout h5py (and therefore Keras's H5IOStore) produces --
+# version-0 superblock, version-1 object headers, symbol-table groups (local heap + one level-0 B-tree
+# node + symbol-table nodes of 2 x leafK = 8 entries), contiguous little-endian datasets.  Written so
+# that the trainer can emit `best_autoencoder.keras` / `final_autoencoder.keras` / `encoder.keras`
+# (CAE_improved_modeltrain.py:271,299-300) without h5py or Keras; tests open the result with the real
+# HDF5 library (conda h5py) as well as with the reader above.
+# =================================================================================================
+_LEAF_K, _INTERNAL_K = 4, 16
+_H5HL_FREE_NULL = 1                     # "end of free list" sentinel of the local heap (H5HLprivate.h)
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * ((8 - len(b) % 8) % 8)
+
+
+def _msg(mtype: int, data: bytes, flags: int = 0) -> bytes:
+    data = _pad8(data)
+    return mtype.to_bytes(2, "little") + len(data).to_bytes(2, "little") + bytes([flags, 0, 0, 0]) + data
+
+
+def _object_header(msgs) -> bytes:
+    body = b"".join(msgs)
+    # version 1, reserved, #messages, reference count 1, header size; 4 bytes of padding align the messages to 8
+    return bytes([1, 0]) + len(msgs).to_bytes(2, "little") + (1).to_bytes(4, "little") + len(body).to_bytes(4, "little") + b"\0" * 4 + body
+
+
+def _datatype_msg(dt: np.dtype) -> bytes:
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        size = dt.itemsize
+        expb, manb, bias = (8, 23, 127) if size == 4 else (11, 52, 1023)
+        head = bytes([0x11, 0x20, 8 * size - 1, 0]) + size.to_bytes(4, "little")       # class 1 (float) v1; LE, implied-msb mantissa; sign bit
+        props = (0).to_bytes(2, "little") + (8 * size).to_bytes(2, "little") + bytes([manb, expb, 0, manb]) + bias.to_bytes(4, "little")
+        return head + props
+    if dt.kind in "iu" and dt.itemsize in (1, 2, 4, 8):
+        size = dt.itemsize
+        head = bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0]) + size.to_bytes(4, "little")   # class 0 (fixed point) v1; LE; signed bit
+        return head + (0).to_bytes(2, "little") + (8 * size).to_bytes(2, "little")
+    raise H5Error(f"dtype {dt} is not supported by the writer")
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(b"\0" * 96)              # superblock, filled in last
+
+    def alloc(self, data: bytes) -> int:
+        self.buf += b"\0" * ((8 - len(self.buf) % 8) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def dataset(self, arr: np.ndarray) -> int:
+        a = np.asarray(arr)
+        if not a.flags.c_contiguous:
+            a = a.copy(order="C")                     # (np.ascontiguousarray would turn a scalar into shape (1,))
+        if a.dtype.byteorder == ">":
+            a = a.astype(a.dtype.newbyteorder("<"))
+        raw = a.tobytes()
+        data_addr = self.alloc(raw) if raw else UNDEF
+        space = bytes([1, a.ndim, 0, 0, 0, 0, 0, 0]) + b"".join(int(d).to_bytes(8, "little") for d in a.shape)
+        fill = bytes([2, 2, 2, 0])                    # version 2; allocate late; write fill value if set; none defined
+        layout = bytes([3, 1]) + data_addr.to_bytes(8, "little") + len(raw).to_bytes(8, "little")
+        return self.alloc(_object_header([_msg(0x0001, space), _msg(0x0003, _datatype_msg(a.dtype), flags=1), _msg(0x0005, fill),
+                                          _msg(0x0008, layout)]))
+
+    def group(self, tree: dict):
+        """tree: {name: ndarray | dict} -> (object header address, B-tree address, heap address)."""
+        names = sorted(tree, key=lambda s: s.encode())                     # symbol-table order = strcmp order
+        if len(names) > 2 * _LEAF_K * 2 * _INTERNAL_K:
+            raise H5Error("too many links in one group for a single B-tree node")
+        kids = {}
+        for n in names:
+            v = tree[n]
+            kids[n] = self.group(v) if isinstance(v, dict) else (self.dataset(np.asarray(v)), None, None)
+        # local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8
+        seg = bytearray(b"\0" * 8)
+        off = {}
+        for n in names:
+            off[n] = len(seg)
+            seg += _pad8(n.encode() + b"\0")
+        seg_addr = self.alloc(bytes(seg))
+        heap = b"HEAP" + bytes(4) + len(seg).to_bytes(8, "little") + _H5HL_FREE_NULL.to_bytes(8, "little") + seg_addr.to_bytes(8, "little")
+        heap_addr = self.alloc(heap)
+        # symbol-table nodes of up to 2 x leafK entries, one level-0 B-tree node over them
+        keys, children = [0], []
+        per = 2 * _LEAF_K
+        for i in range(0, len(names), per):
+            part = names[i:i + per]
+            node = bytearray(b"SNOD" + bytes([1, 0]) + len(part).to_bytes(2, "little"))
+            for n in part:
+                hdr, bt, hp = kids[n]
+                node += off[n].to_bytes(8, "little") + hdr.to_bytes(8, "little")
+                if bt is not None:
+                    node += (1).to_bytes(4, "little") + bytes(4) + bt.to_bytes(8, "little") + hp.to_bytes(8, "little")
+                else:
+                    node += bytes(4) + bytes(4) + bytes(16)
+            node += bytes(8 + per * 40 - len(node))
+            children.append(self.alloc(bytes(node)))
+            keys.append(off[part[-1]])
+        bt = bytearray(b"TREE" + bytes([0, 0]) + len(children).to_bytes(2, "little") + UNDEF.to_bytes(8, "little") * 2)
+        for i, c in enumerate(children):
+            bt += keys[i].to_bytes(8, "little") + c.to_bytes(8, "little")
+        bt += keys[len(children)].to_bytes(8, "little")
+        bt += bytes(24 + (2 * _INTERNAL_K + 1) * 8 + 2 * _INTERNAL_K * 8 - len(bt))
+        bt_addr = self.alloc(bytes(bt))
+        hdr_addr = self.alloc(_object_header([_msg(0x0011, bt_addr.to_bytes(8, "little") + heap_addr.to_bytes(8, "little"))]))
+        return hdr_addr, bt_addr, heap_addr
+
+    def finish(self, root) -> bytes:
+        hdr, bt, hp = root
+        self.buf += b"\0" * ((8 - len(self.buf) % 8) % 8)
+        sb = bytearray(SIGNATURE)
+        sb += bytes([0, 0, 0, 0, 0, 8, 8, 0])
+        sb += _LEAF_K.to_bytes(2, "little") + _INTERNAL_K.to_bytes(2, "little") + bytes(4)
+        sb += (0).to_bytes(8, "little") + UNDEF.to_bytes(8, "little") + len(self.buf).to_bytes(8, "little") + UNDEF.to_bytes(8, "little")
+        sb += (0).to_bytes(8, "little") + hdr.to_bytes(8, "little") + (1).to_bytes(4, "little") + bytes(4) + bt.to_bytes(8, "little") + hp.to_bytes(8, "little")
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write(tree: dict) -> bytes:
+    """{"group/sub/name": array} (flat, as read() returns) or nested dicts -> the bytes of an HDF5 file.  Empty groups are
+    written for keys whose value is an empty dict."""
+    nested: dict = {}
+    for key, v in tree.items():
+        parts = [p for p in key.split("/") if p]
+        d = nested
+        for p in parts[:-1]:
+            d = d.setdefault(p, {})
+            if not isinstance(d, dict):
+                raise H5Error(f"{key}: a dataset is in the way")
+        if isinstance(v, dict):
+            sub = d.setdefault(parts[-1], {})
+            for k2, v2 in (write_flatten(v)).items():
+                sub[k2] = v2
+        else:
+            d[parts[-1]] = v
+    w = _Writer()
+    return w.finish(w.group(nested))
+
+
+def write_flatten(d: dict) -> dict:
+    """Nested dicts stay nested (write() accepts both forms); helper kept separate for clarity."""
+    return d

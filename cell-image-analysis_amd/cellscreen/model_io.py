@@ -261,6 +261,137 @@ def cae_from_keras(path: str) -> CAEWeights:
                       [f32(v[2]) for _, _, v in bns], [f32(v[3]) for _, _, v in bns], hw, n_enc, eps).validate()
 
 
+def _keras_layer_names(n_conv: int, n_enc: int, encoder_only: bool):
+    """Layer sequence of the reference graph (CAE_improved_modeltrain.py:188-216) with the names Keras 3 gives layers
+    created in that order in a fresh session: [(class_name, name, conv/bn index or None)]."""
+    cnt: Dict[str, int] = {}
+
+    def nm(base):
+        k = cnt.get(base, 0)
+        cnt[base] = k + 1
+        return base if k == 0 else f"{base}_{k}"
+    seq = [("InputLayer", nm("input_layer"), None)]
+    for l in range(n_conv):
+        if l > n_enc:
+            seq.append(("UpSampling2D", nm("up_sampling2d"), None))
+        seq.append(("Conv2D", nm("conv2d"), l))
+        if l < n_conv - 1 or encoder_only:
+            seq.append(("BatchNormalization", nm("batch_normalization"), l))
+        if l < n_enc:
+            seq.append(("MaxPooling2D", nm("max_pooling2d"), None))
+    return seq
+
+
+def _keras_config(w: CAEWeights, seq) -> dict:
+    """config.json of the Functional model in the Keras 3 serialization layout (keras/src/models/functional.py,
+    saving/serialization_lib.py as published).  Not cross-checked against a Keras install (none exists here)."""
+    H, W = w.input_hw
+    layers = []
+    prev = None
+    for cls, name, idx in seq:
+        if cls == "InputLayer":
+            cfg = {"batch_shape": [None, H, W, 1], "dtype": "float32", "sparse": False, "name": name}
+        elif cls == "Conv2D":
+            last = idx == w.n_conv - 1 and len(w.bn_gamma) < w.n_conv
+            cfg = {"name": name, "trainable": True, "dtype": "float32", "filters": int(w.kernels[idx].shape[3]), "kernel_size": [3, 3],
+                   "strides": [1, 1], "padding": "same", "data_format": "channels_last", "dilation_rate": [1, 1], "groups": 1,
+                   "activation": "sigmoid" if last else "relu", "use_bias": True,
+                   "kernel_initializer": {"module": "keras.initializers", "class_name": "GlorotUniform", "config": {"seed": None}, "registered_name": None},
+                   "bias_initializer": {"module": "keras.initializers", "class_name": "Zeros", "config": {}, "registered_name": None},
+                   "kernel_regularizer": None, "bias_regularizer": None, "activity_regularizer": None, "kernel_constraint": None, "bias_constraint": None}
+        elif cls == "BatchNormalization":
+            cfg = {"name": name, "trainable": True, "dtype": "float32", "axis": -1, "momentum": spec.BN_MOMENTUM, "epsilon": float(w.bn_eps),
+                   "center": True, "scale": True,
+                   "beta_initializer": {"module": "keras.initializers", "class_name": "Zeros", "config": {}, "registered_name": None},
+                   "gamma_initializer": {"module": "keras.initializers", "class_name": "Ones", "config": {}, "registered_name": None},
+                   "moving_mean_initializer": {"module": "keras.initializers", "class_name": "Zeros", "config": {}, "registered_name": None},
+                   "moving_variance_initializer": {"module": "keras.initializers", "class_name": "Ones", "config": {}, "registered_name": None},
+                   "beta_regularizer": None, "gamma_regularizer": None, "beta_constraint": None, "gamma_constraint": None, "synchronized": False}
+        elif cls == "MaxPooling2D":
+            cfg = {"name": name, "trainable": True, "dtype": "float32", "pool_size": [2, 2], "padding": "same", "strides": [2, 2],
+                   "data_format": "channels_last"}
+        else:
+            cfg = {"name": name, "trainable": True, "dtype": "float32", "size": [2, 2], "data_format": "channels_last", "interpolation": "nearest"}
+        entry = {"module": "keras.layers", "class_name": cls, "config": cfg, "registered_name": None, "name": name,
+                 "inbound_nodes": [] if prev is None else [{"args": [{"class_name": "__keras_tensor__", "config": {"keras_history": [prev, 0, 0]}}], "kwargs": {}}]}
+        layers.append(entry)
+        prev = name
+    return {"module": "keras.src.models.functional", "class_name": "Functional",
+            "config": {"name": "functional", "trainable": True, "layers": layers,
+                       "input_layers": [[seq[0][1], 0, 0]], "output_layers": [[prev, 0, 0]]},
+            "registered_name": "Functional",
+            "build_config": {"input_shape": None},
+            "compile_config": {"optimizer": {"module": "keras.optimizers", "class_name": "Adam",
+                                             "config": {"name": "adam", "learning_rate": spec.ADAM_LR, "beta_1": spec.ADAM_B1, "beta_2": spec.ADAM_B2,
+                                                        "epsilon": spec.ADAM_EPS, "amsgrad": False}, "registered_name": None},
+                               "loss": "mse", "loss_weights": None, "metrics": ["mae"], "weighted_metrics": None, "run_eagerly": False,
+                               "steps_per_execution": 1, "jit_compile": False}}
+
+
+def cae_to_keras(path: str, w: CAEWeights) -> None:
+    """Writes a weight set as a Keras-3 `.keras` archive -- the files the reference's trainer leaves
+    (`best_autoencoder.keras`, `final_autoencoder.keras`: the full autoencoder; `encoder.keras`: a weight set with
+    n_conv == n_enc; CAE_improved_modeltrain.py:271,299-300) -- without Keras or h5py: zip of metadata.json, config.json
+    and model.weights.h5 (cellscreen/h5lite.py writes the HDF5 bytes; variables of layer k as
+    layers/<snake_case class>[_<n>]/vars/<i>, Conv2D = [kernel HWIO, bias], BatchNormalization = [gamma, beta, moving_mean,
+    moving_variance], empty `vars` groups for the weightless layers).  Reads back bit-identically through cae_from_keras
+    and opens with the real HDF5 library (tests); the JSON follows the published Keras 3 serialization and has not been
+    loaded by a Keras install (there is none here)."""
+    import zipfile
+    from datetime import datetime
+    from . import h5lite
+    w.validate()
+    encoder_only = w.n_conv == w.n_enc
+    seq = _keras_layer_names(w.n_conv, w.n_enc, encoder_only)
+    tree: Dict[str, object] = {}
+    for cls, name, idx in seq:
+        if cls == "Conv2D":
+            tree[f"layers/{name}/vars/0"] = np.ascontiguousarray(w.kernels[idx], dtype=np.float32)
+            tree[f"layers/{name}/vars/1"] = np.ascontiguousarray(w.biases[idx], dtype=np.float32)
+        elif cls == "BatchNormalization":
+            for i, a in enumerate((w.bn_gamma[idx], w.bn_beta[idx], w.bn_mean[idx], w.bn_var[idx])):
+                tree[f"layers/{name}/vars/{i}"] = np.ascontiguousarray(a, dtype=np.float32)
+        else:
+            tree[f"layers/{name}/vars"] = {}
+    tree["vars"] = {}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = path + ".tmp"
+    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_DEFLATED) as z:
+        z.writestr("metadata.json", json.dumps({"keras_version": "3.3.3", "date_saved": datetime.now().strftime("%Y-%m-%d@%H:%M:%S"),
+                                                "written_by": "cellscreen.model_io.cae_to_keras (no Keras install)"}))
+        z.writestr("config.json", json.dumps(_keras_config(w, seq)))
+        z.writestr("model.weights.h5", h5lite.write(tree))
+    os.replace(tmp, path)
+
+
+def has_native_files(model_dir: str) -> bool:
+    return os.path.exists(os.path.join(model_dir, spec.NATIVE_CAE))
+
+
+def has_reference_files(model_dir: str) -> bool:
+    return all(os.path.exists(os.path.join(model_dir, f)) for f in spec.REF_MODEL_FILES)
+
+
+def ensure_native_model_dir(model_dir: str) -> str:
+    """What ProductionMutantScreening(model_dir) is handed may be the reference's six files (improved_detection.py:28-41)
+    rather than the native set: convert them (in place; into a fresh temporary directory when model_dir is read-only)
+    and return the directory cs_model_load should read.  A native set that is OLDER than the reference files it sits
+    beside is refreshed."""
+    native = has_native_files(model_dir)
+    if not has_reference_files(model_dir):
+        return model_dir                               # native only, or nothing: cs_model_load reports what is missing
+    if native:
+        newest_ref = max(os.path.getmtime(os.path.join(model_dir, f)) for f in spec.REF_MODEL_FILES)
+        if os.path.getmtime(os.path.join(model_dir, spec.NATIVE_CAE)) >= newest_ref and \
+                os.path.exists(os.path.join(model_dir, spec.NATIVE_DETECTOR)):
+            return model_dir
+    try:
+        return convert_reference_model_dir(model_dir)
+    except OSError:
+        import tempfile
+        return convert_reference_model_dir(model_dir, tempfile.mkdtemp(prefix="cellscreen_model_"))
+
+
 def convert_reference_model_dir(model_dir: str, out_dir: Optional[str] = None) -> str:
     """The six files load_trained_models reads (improved_detection.py:28-41) -> the native file set
     (cae.bin, detector.bin, manifest.json) next to them (or in out_dir).  Needs scikit-learn for the pickles,

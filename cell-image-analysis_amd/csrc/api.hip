@@ -1004,6 +1004,13 @@ int cs_profile_reset(cs_model* m)
     return CS_OK;
 }
 
+int cs_model_wait_stream(cs_model* m, void* hip_stream)
+{
+    if (!m) return fail(CS_ERR_INVALID, "model handle is NULL");
+    HIPCHK(hipSetDevice(m->device));
+    return wait_on_stream(m->stream, hip_stream);
+}
+
 int cs_profile_kernel_count(void) { return K_COUNT; }
 
 const char* cs_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }

@@ -52,6 +52,20 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Orders `mine` (a handle's private stream) after everything enqueued so far on `other` (the caller's stream:
+// torch's current stream, an RCCL stream, ...): the cs_*_wait_stream entry points.  other == nullptr is the
+// legacy default stream, with which a hipStreamNonBlocking stream is NOT implicitly ordered either.
+inline int wait_on_stream(hipStream_t mine, void* other)
+{
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)other);
+    if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
+    (void)hipEventDestroy(ev);                 // released once the recorded work has completed
+    if (e != hipSuccess) return fail(CS_ERR_HIP, "ordering the handle's stream after the caller's failed: %s", hipGetErrorString(e));
+    return CS_OK;
+}
+
 int upload(DevBuf& d, const void* src, size_t bytes);
 int check_arch(const cs_cae_weights* w, int expect_convs, const char* what);
 int require_gfx950(int device_id);

@@ -558,6 +558,13 @@ int cs_fit_create(int device_id, cs_fit** out)
     return CS_OK;
 }
 
+int cs_fit_wait_stream(cs_fit* f, void* hip_stream)
+{
+    if (!f) return fail(CS_ERR_INVALID, "fit handle is NULL");
+    HIPCHK(hipSetDevice(f->device));
+    return wait_on_stream(f->stream, hip_stream);
+}
+
 void cs_fit_free(cs_fit* f)
 {
     if (!f) return;

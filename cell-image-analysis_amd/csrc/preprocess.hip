@@ -440,6 +440,13 @@ int cs_preproc_create(int device_id, cs_preproc** out)
     return CS_OK;
 }
 
+int cs_preproc_wait_stream(cs_preproc* p, void* hip_stream)
+{
+    if (!p) return fail(CS_ERR_INVALID, "preprocess handle is NULL");
+    HIPCHK(hipSetDevice(p->device));
+    return wait_on_stream(p->stream, hip_stream);
+}
+
 void cs_preproc_free(cs_preproc* p)
 {
     if (!p) return;

@@ -160,6 +160,13 @@ int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int dev
     return CS_OK;
 }
 
+int cs_train_wait_stream(cs_trainer* t, void* hip_stream)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer handle is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    return wait_on_stream(t->stream, hip_stream);
+}
+
 void cs_train_free(cs_trainer* t)
 {
     if (!t) return;

@@ -41,6 +41,13 @@
  *     `*_kind` says where it lives: CS_MEM_HOST (pageable or pinned host memory) or
  *     CS_MEM_DEVICE (memory of the handle's device, e.g. a torch tensor's data_ptr()).
  *   - Calls are synchronous: outputs are complete when the call returns.
+ *   - Device INPUTS must be complete before the call: a handle works on its own non-blocking HIP
+ *     stream, which is not ordered with any stream of the caller.  If a CS_MEM_DEVICE buffer (or a
+ *     gradient buffer given to cs_train_set_grad_buffer) was produced by work still in flight on
+ *     another stream -- a torch kernel, an RCCL collective -- either synchronise that stream, or
+ *     call cs_model_wait_stream / cs_train_wait_stream / cs_fit_wait_stream /
+ *     cs_preproc_wait_stream with it first (the Python wrappers do, with torch's current stream):
+ *     the handle's next work then starts after everything enqueued on that stream so far.
  *   - Layouts: crops [n][H][W] fp32 (the trailing channel of 1 is implicit, as
  *     np.expand_dims at improved_detection.py:122 adds it); conv kernels HWIO
  *     [3][3][cin][cout] as Keras stores them; features [n][h*w*c] in (h,w,c) order
@@ -157,6 +164,9 @@ int cs_model_load(const char *model_dir, int device_id, cs_model **out);
 int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights *encoder,
                          const cs_detector_params *detector, int device_id, cs_model **out);
 void cs_model_free(cs_model *m);
+/* Orders the handle's stream after all work enqueued so far on `hip_stream` (a hipStream_t; NULL = the legacy
+ * default stream).  See "Device INPUTS" above.  Same for the three other handle types. */
+int cs_model_wait_stream(cs_model *m, void *hip_stream);
 int cs_model_get_info(const cs_model *m, cs_model_info *info);
 /* Cells per internal pass (workspace ~0.4 MB per cell for the reference graph).  Default: automatic -- 16,384 for
  * host input (pipelined staging), up to 65,536 for device-resident input (a ~28 GB workspace); this call fixes it. */
@@ -212,6 +222,7 @@ typedef enum cs_pixel_type { CS_PIX_U8 = 0, CS_PIX_U16 = 1 } cs_pixel_type;   /*
 
 int cs_preproc_create(int device_id, cs_preproc **out);
 void cs_preproc_free(cs_preproc *p);
+int cs_preproc_wait_stream(cs_preproc *p, void *hip_stream);
 /* pixels:  ragged buffer of n_pixels elements (pixels_kind: host or device); crop i is the
  *          row-major heights[i] x widths[i] block at element offsets[i].  offsets must ascend
  *          and crops must not overlap.  offsets/heights/widths are host arrays of length n.
@@ -250,6 +261,7 @@ int cs_preproc_last_timing(const cs_preproc *p, double *kernel_ms, int64_t *pixe
 typedef struct cs_fit cs_fit;
 int cs_fit_create(int device_id, cs_fit **out);
 void cs_fit_free(cs_fit *f);
+int cs_fit_wait_stream(cs_fit *f, void *hip_stream);
 int cs_fit_scaler(cs_fit *f, const float *features, int64_t n, int32_t n_features, int kind, float *center, double *scale);
 int cs_fit_pca_moments(cs_fit *f, const float *features, int64_t n, int32_t n_features, int kind, const float *center,
                        const double *scale, float *mean, double *scatter);
@@ -293,6 +305,7 @@ int cs_train_param_count(int64_t *n_trainable, int64_t *n_moving);
 /* init: starting weights + moving statistics (create_improved_autoencoder, :184-229). */
 int cs_train_create(const cs_cae_weights *init, const cs_train_cfg *cfg, int device_id, cs_trainer **out);
 void cs_train_free(cs_trainer *t);
+int cs_train_wait_stream(cs_trainer *t, void *hip_stream);
 /* One fit() batch: forward (BN batch statistics, moving-average update), loss = mean((out-y)^2),
  * mae = mean|out-y|, backward, Adam update with learning rate lr.  x = network input (the
  * augmented image of datagen.flow(X_train, X_train), :287), y = target; [batch][H][W] fp32. */
