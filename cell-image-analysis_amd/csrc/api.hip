@@ -32,6 +32,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
+    DevBuf c12w1;          // conv1's fragments for the fused kernel (negated for filters with a negative BN scale)
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -233,9 +234,15 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             rc = upload(set.winocs[l], tmp.data(), tmp.size() * sizeof(float));
             if (rc) return rc;
         }
+        if (l == 0) {
+            tmp.resize(pack_conv12_conv1_fragments(nullptr, nullptr, nullptr));
+            pack_conv12_conv1_fragments(w->kernel[l], ep.data() + cout, tmp.data());
+            rc = upload(set.c12w1, tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+        }
         if (l == 1) {
-            tmp.resize(pack_conv12_fragments(nullptr, nullptr));
-            pack_conv12_fragments(w->kernel[l], tmp.data());
+            tmp.resize(pack_conv12_fragments(nullptr, nullptr, nullptr));
+            pack_conv12_fragments(w->kernel[l], ep.data() + cout, tmp.data());
             rc = upload(set.c12, tmp.data(), tmp.size() * sizeof(float));
             if (rc) return rc;
         }
@@ -423,7 +430,7 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     const bool fused12 = m->fuse12 && m->use_wino && first == 0 && last >= 1;
     if (fused12)
         LAUNCH(K_CONV12_FUSED, nc,
-               launch_conv12_fused(x, set.wfrag[0].as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
+               launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
                                    m->act[1].as<float>(), nc, m->stream));
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();

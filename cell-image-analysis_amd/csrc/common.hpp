@@ -38,11 +38,12 @@ size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* d
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
 size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
-// conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag / ep1 are conv1's
-// pack_conv_fragments / epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
+// conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
+// pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
                                int64_t n_cells, hipStream_t stream);
-size_t pack_conv12_fragments(const float* hwio, float* dst);
+size_t pack_conv12_fragments(const float* hwio, const float* bn_scale, float* dst);
+size_t pack_conv12_conv1_fragments(const float* hwio, const float* bn_scale, float* dst);
 // conv5 (layer 4) / conv6 (layer 5), the upsample-fed decoder convs, as four Winograd F(2x2,2x2) phase convs: conv_wino_up.hip
 hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);

@@ -24,10 +24,12 @@
 //              point (the ring's 8 consumed slots + a 16 KB area).
 //   P4 Y=sA    column fold of the wave's two output rows over all six columns, bias -> ReLU -> BN -> 2x2
 //              max (those two rows are one pool row), store p2.
-// LDS map: V 73,728 | ring 10 x 34 x 32 x 4 = 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008.
+// LDS map: V 73,728 | ring 10 x 34 x 32 x 4 = 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008 | conv1 fragments and
+// epilogue constants 3,072.
 #include "common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace cs {
 
@@ -44,19 +46,24 @@ constexpr int INP_BYTES = 66 * INP_STRIDE * 4;
 constexpr int OFF_RING = V_BYTES;
 constexpr int OFF_E2 = OFF_RING + RING_BYTES;
 constexpr int OFF_INP = OFF_E2 + E2_BYTES;
-constexpr int LDS_BYTES = OFF_INP + INP_BYTES;
+constexpr int OFF_B1 = OFF_INP + INP_BYTES;            // conv1's B fragments [2 slices][3 K steps][64 lanes]
+constexpr int OFF_EP1 = OFF_B1 + 2 * 3 * 64 * 4;       // conv1 epilogue {bias, bn scale, bn shift, sign} per channel
+constexpr int OFF_EP2 = OFF_EP1 + 32 * 16;             // conv2 epilogue, same
+constexpr int LDS_BYTES = OFF_EP2 + 64 * 16;
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_RING % 16 == 0 && OFF_E2 % 16 == 0 && OFF_INP % 16 == 0, "LDS map");
 
 __device__ __forceinline__ float vmaxf(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float vminf(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
-// bias -> ReLU -> BN of the pooled raw sum: the map is monotone (direction = sign of the BN scale), so
-// the max over the window of the mapped values is the map of the window's max (resp. min)
-__device__ __forceinline__ float pool_post(float a, float b, float c, float d, float bias, float bns, float bnt)
+// bias -> ReLU -> BN -> 2x2 max of a window of raw conv sums.  The map v -> BN(relu(v + bias)) is monotone with the
+// direction of the BN scale's sign, so the max over the window of the mapped values is the map of the window's max
+// (scale >= 0) or min (scale < 0).  The min case is folded into the weights: channels with a negative BN scale carry
+// NEGATED kernels (pack_conv12_*), so the MFMAs produce -z exactly (negation commutes with every fp32 rounding), the
+// window's min is -max(-z), and v = sgn * max + bias with sgn = -1 for those channels -- one fma, no second path.
+__device__ __forceinline__ float pool_post(float a, float b, float c, float d, float sgn, float bias, float bns, float bnt)
 {
-    const float mx = vmaxf(vmaxf(a, b), vmaxf(c, d)), mn = vminf(vminf(a, b), vminf(c, d));
-    float v = (bns >= 0.0f ? mx : mn) + bias;
-    v = fmaxf(v, 0.0f);
+    const float mx = vmaxf(vmaxf(a, b), vmaxf(c, d));
+    const float v = vmaxf(fmaf(sgn, mx, bias), 0.0f);   // raw v_max: never NaN for finite inputs, no canonicalisation needed
     return fmaf(v, bns, bnt);
 }
 
@@ -73,10 +80,31 @@ __device__ __forceinline__ void bt6(const float d[6], float o[6])
     o[4] = fmaf(-2.0f, t4, t3);
 }
 
+// DIAG: diagnostic build (CS_C12_DIAG=1) that stamps s_memtime at the phase boundaries of every group and sums the
+// differences per wave: [0] P1, [1] wait at barrier 1, [2] P2, [3] barrier 2, [4] P3, [5] barrier 3, [6] P4, [7] barrier 4.
+// Never used for results or timing.
+__device__ __forceinline__ unsigned long long c12_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define C12_STAMP(k)                                                       \
+    if constexpr (DIAG) {                                                  \
+        const unsigned long long t__ = c12_stamp();                        \
+        dg[k] += t__ - dt;                                                 \
+        dt = t__;                                                          \
+    }
+
+template <bool DIAG>
 __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1frag,
                                                               const float* __restrict__ ep1, const float* __restrict__ ufrag,
-                                                              const float* __restrict__ ep2, float* __restrict__ p2, long n_cells)
+                                                              const float* __restrict__ ep2, float* __restrict__ p2, long n_cells,
+                                                              unsigned long long* __restrict__ diag)
 {
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ring = (float*)(smem + OFF_RING);
     float* const inp = (float*)(smem + OFF_INP);
@@ -84,96 +112,121 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
-    // ---- P3 operands: U of this wave's 18 transform points, all 32 input channels, its 16 filters
+    // ---- P3 operands: U of this wave's 18 transform points, all 32 input channels, its 16 filters.  These 144 VGPRs
+    // are the kernel's register budget; every other per-lane constant is kept in LDS or recomputed per group.
     const int gcol = w & 1, sl = w >> 1;
     float U[144];
 #pragma unroll
     for (int s = 0; s < 144; ++s) U[s] = ufrag[((size_t)w * 144 + s) * 64 + lane];
-    const int co = sl * 16 + li;
-    float bias2 = ep2[co], bns2 = ep2[64 + co], bnt2 = ep2[128 + co];
-    // ---- P1 operands: conv1 weights of slice s1 (K = 9 padded to 12), tile column xt
-    const int xt = w & 3, s1 = w >> 2;
-    float B1[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) B1[s] = w1frag[((size_t)s1 * 3 + s) * 64 + lane];
-    const int c1 = s1 * 16 + li;
-    float bias1 = ep1[c1], bns1 = ep1[32 + c1], bnt1 = ep1[64 + c1];
-    // touch the loop invariants here so that the compiler's wait for these loads is not inside the loop
-#pragma unroll
-    for (int s = 0; s < 144; ++s) asm volatile("" : "+v"(U[s]));
-    asm volatile("" : "+v"(B1[0]), "+v"(B1[1]), "+v"(B1[2]), "+v"(bias1), "+v"(bns1), "+v"(bnt1), "+v"(bias2), "+v"(bns2), "+v"(bnt2));
+    for (int s = 0; s < 144; ++s) asm volatile("" : "+v"(U[s]));     // first use inside the loop would put the wait for these loads there
+    const int xt = w & 3, s1 = w >> 2;                                // P1: tile column, 16-channel slice of conv1
 
     const long my_cells = (n_cells - blockIdx.x + gridDim.x - 1) / gridDim.x;
     if (my_cells <= 0) return;
 
-    // conv1 A operand: lane (pixel li, k = 4 s + kq) reads tap (k / 3, k % 3); the padded taps k >= 9 carry zero
-    // weights and read tap 0 (finite whenever the true taps are)
-    int toff[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int k = 4 * s + kq, kk = k < 9 ? k : 0;
-        toff[s] = (kk / 3) * INP_STRIDE + (kk % 3) + 16 * xt + li + 3;
-    }
-    // conv1 pooled outputs of this lane: ring columns 8 xt + 2 kq + {0,1} (+1: halo), channel c1
-    const int pwoff = (8 * xt + 2 * kq + 1) * 32 + c1;
-    // crop staging: thread -> rows (tid >> 4) and +32, 16-byte column tid & 15
-    const int srow = tid >> 4, sc16 = tid & 15;
-    const int soff = (srow + 1) * INP_STRIDE + 4 + 4 * sc16;
-    // P2: thread (tile, channel)
-    const int tile = tid >> 5, ch = tid & 31, trow = w >> 2, tx = tile & 7;
-    const int roff = (4 * tx) * 32 + ch;                              // first patch column of the tile, this channel
-    const int vq = ch >> 4, vkq = (ch >> 2) & 3, vj = ch & 3;
-    const int voff = (((vq * 4 + vkq) * 16 + ((tile + 2 * (2 * vq + (vkq >> 1))) & 15)) * 4 + vj) * 4;   // bytes
-    // P3: A operand slots of lane (tile li, channel quad kq) for q = 0, 1
-    const int aoff0 = ((0 * 4 + kq) * 16 + ((li + 2 * (0 + (kq >> 1))) & 15)) * 16;
-    const int aoff1 = ((1 * 4 + kq) * 16 + ((li + 2 * (2 + (kq >> 1))) & 15)) * 16;
-
-    // ---- LDS: zero everything once (halo columns / rows of the crop and the ring are never written again)
+    // ---- LDS: zero everything once (halo columns / rows of the crop and the ring are never written again), then the
+    // small tables: conv1's B fragments [2][3][64] and the epilogue constants {bias, bn scale, bn shift, sign} per channel
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
+    if (tid < 384) ((float*)(smem + OFF_B1))[tid] = w1frag[tid];
+    if (tid < 32) {
+        const float sc = ep1[32 + tid];
+        ((f32x4*)(smem + OFF_EP1))[tid] = f32x4{ep1[tid], sc, ep1[64 + tid], sc >= 0.0f ? 1.0f : -1.0f};
+    }
+    if (tid >= 64 && tid < 128) {
+        const int c = tid - 64;
+        const float sc = ep2[64 + c];
+        ((f32x4*)(smem + OFF_EP2))[c] = f32x4{ep2[c], sc, ep2[128 + c], sc >= 0.0f ? 1.0f : -1.0f};
+    }
     {
+        const int srow = tid >> 4, sc16 = tid & 15;
         const float* src = x + (size_t)blockIdx.x * 4096 + srow * 64 + 4 * sc16;
-        *(f32x4*)(inp + soff) = *(const f32x4*)src;
-        *(f32x4*)(inp + soff + 32 * INP_STRIDE) = *(const f32x4*)(src + 32 * 64);
+        float* dst = inp + (srow + 1) * INP_STRIDE + 4 + 4 * sc16;
+        *(f32x4*)dst = *(const f32x4*)src;
+        *(f32x4*)(dst + 32 * INP_STRIDE) = *(const f32x4*)(src + 32 * 64);
     }
     __syncthreads();
 
     for (long ci = 0; ci < my_cells; ++ci) {
         const long cell = blockIdx.x + ci * gridDim.x;
         const bool has_next = ci + 1 < my_cells;
+#pragma unroll 1
         for (int g = 0; g < 4; ++g) {
+            // per-lane offsets are recomputed from a laundered copy of the thread id in every group: hoisted out of the loop
+            // they would be ~15 long-lived VGPRs next to the 144 of U, and the kernel would spill
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int l2 = t2 & 63, li2 = l2 & 15, kq2 = l2 >> 4;
+            if constexpr (DIAG) dt = c12_stamp();
             // ================= P1: the group's new p1 rows (ring positions q; p1 row y = q - 1; q = 0, 33: zero rows)
             f32x4 stg0 = {0.0f, 0.0f, 0.0f, 0.0f}, stg1 = stg0;
             if (g == 3 && has_next) {   // next cell's crop: in flight during this phase, written to LDS in P2
-                const float* src = x + (size_t)(cell + gridDim.x) * 4096 + srow * 64 + 4 * sc16;
+                const float* src = x + (size_t)(cell + gridDim.x) * 4096 + (t2 >> 4) * 64 + 4 * (t2 & 15);
                 stg0 = *(const f32x4*)src;
                 stg1 = *(const f32x4*)(src + 32 * 64);
             }
-            const int q0 = g == 0 ? 0 : 8 * g + 2, nq = g == 0 ? 10 : 8;
-            for (int i = 0; i < nq; ++i) {
-                const int q = q0 + i;
-                const int slot = q % RING_SLOTS;
-                float* const row = ring + slot * RING_ROWF;
-                if (q == 0 || q == 33) {
-                    if (tid < 256) *(f32x4*)(row + 32 + 4 * tid) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    continue;
-                }
-                const float* a = inp + (2 * (q - 1)) * INP_STRIDE;
-                f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            {
+                // conv1 A operand: lane (pixel li, k = 4 s + kq) reads tap (k / 3, k % 3); the padded taps k >= 9 carry zero
+                // weights and read tap 0 (finite whenever the true taps are)
+                int toff[3];
+                float B1[3];
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    const float a0 = a[toff[s]];
-                    const float a1 = a[toff[s] + INP_STRIDE];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B1[s], acc1, 0, 0, 0);
+                    const int k = 4 * s + kq2, kk = k < 9 ? k : 0;
+                    toff[s] = (kk / 3) * INP_STRIDE + (kk % 3) + 16 * xt + li2 + 3;
+                    B1[s] = *(const float*)(smem + OFF_B1 + ((s1 * 3 + s) * 64 + l2) * 4);
                 }
-                row[pwoff] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], bias1, bns1, bnt1);
-                row[pwoff + 32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], bias1, bns1, bnt1);
+                const int c1 = s1 * 16 + li2;
+                const f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);           // bias, bn scale, bn shift, sign
+                // pooled outputs of this lane: ring columns 8 xt + 2 kq + {0,1} (+1: halo), channel c1
+                const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
+                auto p1_row = [&](int q) {
+                    float* const row = ring + (q % RING_SLOTS) * RING_ROWF + pwoff;
+                    const float* a = inp + (2 * (q - 1)) * INP_STRIDE;
+                    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const float a0 = a[toff[s]];
+                        const float a1 = a[toff[s] + INP_STRIDE];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B1[s], acc1, 0, 0, 0);
+                    }
+                    row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                    row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                };
+                // rows q = 8 g + 2 .. 8 g + 9 of every group (g = 3: q = 33 is the bottom zero row), plus q = 0 (zero) and q = 1
+                // for g = 0.  Four rows at a time are unrolled so that their LDS reads are in flight before the first MFMA and
+                // the MFMA chains of different rows interleave (a rolled loop exposed read + MFMA latency per row).
+                if (g == 0) {
+                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
+                    p1_row(1);
+                }
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const int qb = 8 * g + 2 + 4 * h;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) p1_row(qb + i);
+                    if (qb + 3 == 33) {
+                        if (t2 < 256) *(f32x4*)(ring + (33 % RING_SLOTS) * RING_ROWF + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    } else {
+                        p1_row(qb + 3);
+                    }
+                }
             }
+            C12_STAMP(0)
             __syncthreads();
+            C12_STAMP(1)
 
             // ================= P2: V = B^T d B of this thread's (tile, channel) patch
             {
+                const int tile = t2 >> 5, ch = t2 & 31, trow = w >> 2, tx = tile & 7;
+                const int roff = (4 * tx) * 32 + ch;                              // first patch column of the tile, this channel
+                const int vq = ch >> 4, vkq = (ch >> 2) & 3, vj = ch & 3;
+                // V is stored in the A-operand order of P3: [point][q][kq][slot][4 channels], slot = tile rotated by
+                // 2 (2 q + (kq >> 1)): the writes of a half wave (one tile, 32 channels) then spread over 16 banks x 2 (free for
+                // ds_write_b32) instead of 4 banks x 8, and every 16-lane group of a ds_read_b128 still covers 16 distinct slots
+                const int voff = (((vq * 4 + vkq) * 16 + ((tile + 2 * (2 * vq + (vkq >> 1))) & 15)) * 4 + vj) * 4;   // bytes
                 float d[6][6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
@@ -183,8 +236,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     for (int j = 0; j < 6; ++j) d[i][j] = r[j * 32];
                 }
                 if (g == 3 && has_next) {   // the crop buffer is dead since the barrier above
-                    *(f32x4*)(inp + soff) = stg0;
-                    *(f32x4*)(inp + soff + 32 * INP_STRIDE) = stg1;
+                    float* dst = inp + ((t2 >> 4) + 1) * INP_STRIDE + 4 + 4 * (t2 & 15);
+                    *(f32x4*)dst = stg0;
+                    *(f32x4*)(dst + 32 * INP_STRIDE) = stg1;
                 }
                 // rows first (B^T d), then columns ((B^T d) B): V[r][c]
                 float t[6][6];
@@ -205,51 +259,53 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     for (int c = 0; c < 6; ++c) *(float*)(smem + (r * 6 + c) * 2048 + voff) = o[c];
                 }
             }
+            C12_STAMP(2)
             __syncthreads();
+            C12_STAMP(3)
 
             // ================= P3: M = V U on the matrix pipe, row fold in registers
             f32x4 own[3][2];
             {
+                // A operand slots of lane (tile li, channel quad kq) for q = 0, 1
+                const int aoff0 = ((0 * 4 + kq2) * 16 + ((li2 + 2 * (0 + (kq2 >> 1))) & 15)) * 16;
+                const int aoff1 = ((1 * 4 + kq2) * 16 + ((li2 + 2 * (2 + (kq2 >> 1))) & 15)) * 16;
                 const int e1slot = (8 * g + w) % RING_SLOTS;                        // a consumed ring slot: this wave's exchange area
-                char* const e1 = (char*)(ring + e1slot * RING_ROWF + 32) + lane * 16;
-                char* const e2 = smem + OFF_E2 + w * 2048 + lane * 16;
-                auto mrow = [&](int cc, int r) -> f32x4 {
-                    const int xi = r * 6 + 3 * gcol + cc;
-                    const f32x4 a0 = *(const f32x4*)(smem + xi * 2048 + aoff0);
-                    const f32x4 a1 = *(const f32x4*)(smem + xi * 2048 + aoff1);
-                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                char* const e1 = (char*)(ring + e1slot * RING_ROWF + 32) + l2 * 16;
+                char* const e2 = smem + OFF_E2 + w * 2048 + l2 * 16;
+                // three rows of one column: 6 LDS reads, then 24 MFMAs as three interleaved accumulation chains (an MFMA of a
+                // chain issues 3 x 32 cycles after its predecessor, past the matrix pipe's result latency)
+                auto trio = [&](int cc, int r0, f32x4 (&m)[3]) {
+                    f32x4 a[3][2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], U[(cc * 6 + r) * 8 + j], acc, 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) {
+                        const int xi = (r0 + t) * 6 + 3 * gcol + cc;
+                        a[t][0] = *(const f32x4*)(smem + xi * 2048 + aoff0);
+                        a[t][1] = *(const f32x4*)(smem + xi * 2048 + aoff1);
+                        m[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], U[(cc * 6 + r) * 8 + 4 + j], acc, 0, 0, 0);
-                    return acc;
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int t = 0; t < 3; ++t)
+                                m[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][h][j], U[(cc * 6 + r0 + t) * 8 + 4 * h + j], m[t], 0, 0, 0);
                 };
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
                     // s = A^T m:  s0 = m0 + (m1+m2) + (m3+m4), s1 = (m1-m2) + 2 (m3-m4), s2 = (m1+m2) + 4 (m3+m4),
                     //             s3 = (m1-m2) + 8 (m3-m4) + m5
-                    const f32x4 m1 = mrow(cc, 1), m2 = mrow(cc, 2);
-                    const f32x4 p = m1 + m2, mq = m1 - m2;
-                    const f32x4 m3 = mrow(cc, 3), m4 = mrow(cc, 4);
-                    const f32x4 u = m3 + m4, v = m3 - m4;
-                    f32x4 sa, sb, ta, tb;   // (sa, sb): rows this wave keeps; (ta, tb): rows of the partner
-                    if (gcol == 0) {
-                        const f32x4 m0 = mrow(cc, 0);
-                        sa = m0 + p + u;
-                        sb = mq + 2.0f * v;
-                        ta = p + 4.0f * u;
-                        const f32x4 m5 = mrow(cc, 5);
-                        tb = mq + 8.0f * v + m5;
-                    } else {
-                        const f32x4 m5 = mrow(cc, 5);
-                        sa = p + 4.0f * u;
-                        sb = mq + 8.0f * v + m5;
-                        const f32x4 m0 = mrow(cc, 0);
-                        ta = m0 + p + u;
-                        tb = mq + 2.0f * v;
-                    }
-                    own[cc][0] = sa;
-                    own[cc][1] = sb;
+                    f32x4 ma[3], mb[3];
+                    trio(cc, 0, ma);
+                    const f32x4 p = ma[1] + ma[2], mq = ma[1] - ma[2];
+                    trio(cc, 3, mb);
+                    const f32x4 u = mb[0] + mb[1], v = mb[0] - mb[1];
+                    const f32x4 s0 = ma[0] + p + u, s1 = mq + 2.0f * v, s2 = p + 4.0f * u, s3 = mq + 8.0f * v + mb[2];
+                    // rows (2 gcol, 2 gcol + 1) stay, the other two go to the partner wave.  The asm statements keep the
+                    // compiler from turning this wave-uniform branch into 16 v_cndmask per column.
+                    f32x4 ta, tb;
+                    if (gcol == 0) { asm volatile(""); own[cc][0] = s0; own[cc][1] = s1; ta = s2; tb = s3; }
+                    else           { asm volatile(""); own[cc][0] = s2; own[cc][1] = s3; ta = s0; tb = s1; }
                     if (cc < 2) {
                         *(f32x4*)(e1 + (2 * cc) * 1024) = ta;
                         *(f32x4*)(e1 + (2 * cc + 1) * 1024) = tb;
@@ -259,39 +315,55 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     }
                 }
             }
+            C12_STAMP(4)
             __syncthreads();
+            C12_STAMP(5)
 
             // ================= P4: column fold of this wave's two output rows, epilogue, store
             {
                 const int wp = w ^ 1;
                 const int pslot = (8 * g + wp) % RING_SLOTS;
-                const char* const e1 = (const char*)(ring + pslot * RING_ROWF + 32) + lane * 16;
-                const char* const e2 = smem + OFF_E2 + wp * 2048 + lane * 16;
-                f32x4 y[2][4];
+                const char* const e1 = (const char*)(ring + pslot * RING_ROWF + 32) + l2 * 16;
+                const char* const e2 = smem + OFF_E2 + wp * 2048 + l2 * 16;
+                const int co = sl * 16 + li2;
+                const f32x4 e2v = *(const f32x4*)(smem + OFF_EP2 + co * 16);          // bias, bn scale, bn shift, sign
+                // register r <-> tile 4 kq + r of the group (tile row kq >> 1, tile columns 4 (kq & 1) + r); output rows
+                // (2 gcol, 2 gcol + 1) of a tile are pool row gcol: one base address per lane, the rest immediates
+                float* const obase = p2 + ((((size_t)cell * 16 + 2 * (2 * g + (kq2 >> 1)) + gcol) * 16 + 8 * (kq2 & 1)) * 64 + co);
+                auto finish = [&](auto first_c) {
+                    constexpr bool FIRST = decltype(first_c)::value;
+                    f32x4 y[2][4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 s[6];
-                    const f32x4 pa = *(const f32x4*)(e1 + (0 + i) * 1024), pb = *(const f32x4*)(e1 + (2 + i) * 1024),
-                                pc = *(const f32x4*)(e2 + i * 1024);
-                    if (gcol == 0) { s[0] = own[0][i]; s[1] = own[1][i]; s[2] = own[2][i]; s[3] = pa; s[4] = pb; s[5] = pc; }
-                    else           { s[0] = pa; s[1] = pb; s[2] = pc; s[3] = own[0][i]; s[4] = own[1][i]; s[5] = own[2][i]; }
-                    const f32x4 p = s[1] + s[2], mq = s[1] - s[2], u = s[3] + s[4], v = s[3] - s[4];
-                    y[i][0] = s[0] + p + u;
-                    y[i][1] = mq + 2.0f * v;
-                    y[i][2] = p + 4.0f * u;
-                    y[i][3] = mq + 8.0f * v + s[5];
-                }
-                // register r <-> tile 4 kq + r of the group; rows (2 gcol, 2 gcol + 1) of the tile = pool row gcol
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 pa = *(const f32x4*)(e1 + (0 + i) * 1024), pb = *(const f32x4*)(e1 + (2 + i) * 1024),
+                                    pc = *(const f32x4*)(e2 + i * 1024);
+                        // this wave's columns are 0..2 (FIRST) or 3..5 of the transform domain
+                        const f32x4 s0 = FIRST ? own[0][i] : pa, s1 = FIRST ? own[1][i] : pb, s2 = FIRST ? own[2][i] : pc;
+                        const f32x4 s3 = FIRST ? pa : own[0][i], s4 = FIRST ? pb : own[1][i], s5 = FIRST ? pc : own[2][i];
+                        const f32x4 p = s1 + s2, mq = s1 - s2, u = s3 + s4, v = s3 - s4;
+                        y[i][0] = s0 + p + u;
+                        y[i][1] = mq + 2.0f * v;
+                        y[i][2] = p + 4.0f * u;
+                        y[i][3] = mq + 8.0f * v + s5;
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 4 * kq + r;
-                    const int py = 2 * (2 * g + (t >> 3)) + gcol, px = 2 * (t & 7);
-                    float* o = p2 + (((size_t)cell * 16 + py) * 16 + px) * 64 + co;
-                    o[0] = pool_post(y[0][0][r], y[0][1][r], y[1][0][r], y[1][1][r], bias2, bns2, bnt2);
-                    o[64] = pool_post(y[0][2][r], y[0][3][r], y[1][2][r], y[1][3][r], bias2, bns2, bnt2);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        obase[r * 128] = pool_post(y[0][0][r], y[0][1][r], y[1][0][r], y[1][1][r], e2v[3], e2v[0], e2v[1], e2v[2]);
+                        obase[r * 128 + 64] = pool_post(y[0][2][r], y[0][3][r], y[1][2][r], y[1][3][r], e2v[3], e2v[0], e2v[1], e2v[2]);
+                    }
+                };
+                if (gcol == 0) finish(std::true_type{});
+                else finish(std::false_type{});
             }
+            C12_STAMP(6)
             __syncthreads();   // the exchange area inside the ring is consumed before the next P1 refills those slots
+            C12_STAMP(7)
+        }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) diag[((size_t)blockIdx.x * 8 + w) * 8 + k] = dg[k];
         }
     }
 }
@@ -300,7 +372,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 
 // U = G g G^T of F(4x4,3x3) per (cin, cout), evaluated in double and rounded once.
 // ufrag[wave w = 2 sl + gcol][(cc * 6 + r) * 8 + 4 q + j][lane] = U[row r][col 3 gcol + cc][ci = 16 q + 4 kq + j][co = 16 sl + li]
-size_t pack_conv12_fragments(const float* hwio /* [3][3][32][64] */, float* dst)
+size_t pack_conv12_fragments(const float* hwio /* [3][3][32][64] */, const float* bn_scale /* [64] */, float* dst)
 {
     const size_t total = (size_t)8 * 144 * 64;
     if (!dst) return total;
@@ -318,28 +390,77 @@ size_t pack_conv12_fragments(const float* hwio /* [3][3][32][64] */, float* dst)
                         for (int a = 0; a < 3; ++a)
                             for (int b = 0; b < 3; ++b)
                                 u += G[r][a] * (double)hwio[((size_t)(a * 3 + b) * 32 + ci) * 64 + co] * G[c][b];
+                        if (bn_scale[co] < 0.0f) u = -u;      // the kernel pools -z for these filters (pool_post)
                         dst[((size_t)w * 144 + (cc * 6 + r) * 8 + kk) * 64 + lane] = (float)u;
                     }
     }
     return total;
 }
 
+// conv1's B fragments for the fused kernel: pack_conv_fragments(cin = 1) layout [slice][K step][lane] with the kernels of
+// the filters whose BN scale is negative negated (pool_post).
+size_t pack_conv12_conv1_fragments(const float* hwio /* [3][3][1][32] */, const float* bn_scale /* [32] */, float* dst)
+{
+    const size_t total = (size_t)2 * 3 * 64;
+    if (!dst) return total;
+    for (int nsl = 0; nsl < 2; ++nsl)
+        for (int s = 0; s < 3; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int li = lane & 15, kq = lane >> 4, k = 4 * s + kq, co = nsl * 16 + li;
+                float v = k < 9 ? hwio[(size_t)k * 32 + co] : 0.0f;
+                if (bn_scale[co] < 0.0f) v = -v;
+                dst[((size_t)nsl * 3 + s) * 64 + lane] = v;
+            }
+    return total;
+}
+
+unsigned long long* g_c12_diag = nullptr;
+int g_c12_diag_blocks = 0;
+
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
                                int64_t n_cells, hipStream_t stream)
 {
     static int cus = 0;
+    static const bool diag = getenv("CS_C12_DIAG") != nullptr;
     if (!cus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv12_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         if (cus < 1) cus = 1;
+        if (diag) {
+            if ((e = hipMalloc(&g_c12_diag, (size_t)cus * 64 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_c12_diag_blocks = cus;
+        }
     }
     if (n_cells <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);      // one workgroup per CU (LDS-bound), persistent over cells
-    hipLaunchKernelGGL(conv12_fused_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2, (long)n_cells);
+    if (diag)
+        hipLaunchKernelGGL(conv12_fused_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2, (long)n_cells,
+                           g_c12_diag);
+    else
+        hipLaunchKernelGGL(conv12_fused_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2, (long)n_cells,
+                           (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
 }  // namespace cs
+
+// Diagnostic only (CS_C12_DIAG=1): per-wave phase cycles of the LAST launch of the fused conv1 + conv2 kernel, averaged over waves.
+extern "C" int cs_debug_conv12_diag(double out8[8])
+{
+    using namespace cs;
+    if (!g_c12_diag) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const size_t n = (size_t)g_c12_diag_blocks * 64;
+    unsigned long long* h = new unsigned long long[n];
+    if (hipMemcpy(h, g_c12_diag, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { delete[] h; return -3; }
+    for (int k = 0; k < 8; ++k) out8[k] = 0.0;
+    for (size_t i = 0; i < n; ++i) out8[i % 8] += (double)h[i];
+    for (int k = 0; k < 8; ++k) out8[k] /= (double)(n / 8);
+    delete[] h;
+    return 0;
+}
