@@ -70,6 +70,7 @@ SIGNATURES = {
     "cs_model_load": (_I, [C.c_char_p, _I, C.POINTER(_P)]),
     "cs_model_from_arrays": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSCaeWeights), C.POINTER(CSDetectorParams), _I, C.POINTER(_P)]),
     "cs_model_free": (None, [_P]),
+    "cs_model_wait_stream": (_I, [_P, _P]),
     "cs_model_get_info": (_I, [_P, C.POINTER(CSModelInfo)]),
     "cs_model_set_chunk": (_I, [_P, _L]),
     "cs_screen": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I]),
@@ -80,10 +81,12 @@ SIGNATURES = {
     "cs_svm_decision": (_I, [_P, _P, _L, _I, _P, _P, _I]),
     "cs_preproc_create": (_I, [_I, C.POINTER(_P)]),
     "cs_preproc_free": (None, [_P]),
+    "cs_preproc_wait_stream": (_I, [_P, _P]),
     "cs_preprocess": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _L, C.c_double, _P, _P, _I]),
     "cs_preproc_last_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "cs_fit_create": (_I, [_I, C.POINTER(_P)]),
     "cs_fit_free": (None, [_P]),
+    "cs_fit_wait_stream": (_I, [_P, _P]),
     "cs_fit_scaler": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P]),
     "cs_fit_pca_moments": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P, _P, _P]),
     "cs_fit_project": (_I, [_P, _P, _L, C.c_int32, _I, _P, _P, _P, _P, C.c_int32, _P]),
@@ -100,6 +103,7 @@ SIGNATURES = {
     "cs_train_param_count": (_I, [C.POINTER(_L), C.POINTER(_L)]),
     "cs_train_create": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSTrainCfg), _I, C.POINTER(_P)]),
     "cs_train_free": (None, [_P]),
+    "cs_train_wait_stream": (_I, [_P, _P]),
     "cs_train_step": (_I, [_P, _P, _P, _L, _I, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_forward_backward": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_apply": (_I, [_P, C.c_float]),
@@ -156,6 +160,22 @@ def _ptr(a) -> Optional[int]:
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     raise TypeError(f"cannot take the address of {type(a)}")
+
+
+def order_after_torch(wait_fn, handle, *buffers):
+    """Device buffers handed to the library may still be being produced on torch's current stream (a gather, a
+    cast, an RCCL collective torch has already ordered its stream after); the handle works on its own non-blocking
+    stream.  Make that stream wait for torch's -- an event dependency on the device, no host synchronisation.  A
+    no-op when no buffer is a CUDA tensor (include/cellscreen.h, "Device INPUTS")."""
+    dev = None
+    for b in buffers:
+        if b is not None and not isinstance(b, np.ndarray) and getattr(b, "is_cuda", False):
+            dev = b.device
+            break
+    if dev is None:
+        return
+    import torch
+    check(wait_fn(handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 def mem_kind(a) -> int:

@@ -103,8 +103,7 @@ class Fitter:
         L.check(self._lib.cs_fit_last_ms(self._h, C.byref(v)))
         return v.value
 
-    @staticmethod
-    def _features(features):
+    def _features(self, features):
         if isinstance(features, np.ndarray):
             if features.ndim != 2:
                 raise ValueError(f"features must be (N, F), got {features.shape}")
@@ -113,6 +112,7 @@ class Fitter:
         import torch
         if not (features.is_cuda and features.dtype == torch.float32 and features.is_contiguous() and features.dim() == 2):
             raise ValueError("device features must be a contiguous CUDA float32 tensor (N, F)")
+        L.order_after_torch(self._lib.cs_fit_wait_stream, self._h, features)
         return features, features.data_ptr(), features.shape[0], features.shape[1], MEM_DEVICE
 
     def scaler(self, features) -> Tuple[np.ndarray, np.ndarray]:

@@ -122,6 +122,7 @@ class Engine:
             t = t[..., 0]
         if t.dim() != 3 or tuple(t.shape[1:]) != (self.info.height, self.info.width):
             raise ValueError(f"crops must be (N,{self.info.height},{self.info.width}), got {tuple(t.shape)}")
+        L.order_after_torch(self._lib.cs_model_wait_stream, self._h, t)
         return t, t.shape[0], L.mem_kind(t)
 
     @staticmethod
@@ -187,6 +188,7 @@ class Engine:
         """Fills a torch CUDA tensor (n,H,W) float32 on this engine's device."""
         n = out_tensor.shape[0]
         npix = int(np.prod(out_tensor.shape[1:]))
+        L.order_after_torch(self._lib.cs_model_wait_stream, self._h, out_tensor)     # e.g. after a torch.empty + earlier users
         L.check(self._lib.cs_synth_crops(self._h, seed, first_cell, n, npix, out_tensor.data_ptr()))
         return out_tensor
 

@@ -111,8 +111,9 @@ class Preprocessor:
                 raise ValueError("out must be a contiguous CUDA float32 tensor of shape [n,64,64]")
             res, out_ptr, out_kind = out, out.data_ptr(), MEM_DEVICE
             if want_clahe:
-                clahe = torch.zeros(n_pix, dtype=torch.int16, device=out.device)
+                clahe = torch.zeros(n_pix, dtype=torch.int16, device=out.device)     # gaps between crops read 0; ordered before the kernel below
                 cl_ptr = clahe.data_ptr()
+        L.order_after_torch(self._lib.cs_preproc_wait_stream, self._h, pixels if on_dev else None, out, clahe if out is not None else None)
         L.check(self._lib.cs_preprocess(self._h, pix_ptr, ptype, n_pix, MEM_DEVICE if on_dev else MEM_HOST,
                                         offsets.ctypes.data, heights.ctypes.data, widths.ctypes.data, n,
                                         float(clip_limit), out_ptr, cl_ptr if want_clahe else None, out_kind))

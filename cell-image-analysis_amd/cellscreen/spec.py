@@ -25,6 +25,7 @@ EPOCHS = 100            # :289
 VAL_SPLIT, SPLIT_SEED = 0.2, 42                         # :240
 ES_PATIENCE = 10        # EarlyStopping(patience=10, restore_best_weights=True) :264-269
 RLROP_FACTOR, RLROP_PATIENCE, RLROP_MIN_LR = 0.5, 5, 1e-6   # :276-282
+RLROP_MIN_DELTA = 1e-4  # ReduceLROnPlateau's Keras default min_delta (not passed at :276-282): improvement iff val < best - 1e-4
 PCA_MAX_COMPONENTS = 100                                 # :412
 NU_CONSERVATIVE, NU_MODERATE = 0.05, 0.10                # :421-422
 MIN_TRAINING_CELLS = 500                                 # :491-493

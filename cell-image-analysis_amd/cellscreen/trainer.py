@@ -90,11 +90,13 @@ class Trainer:
         except Exception:
             pass
 
-    @staticmethod
-    def _buf(a):
+    def _buf(self, a):
         if isinstance(a, np.ndarray):
             a = np.ascontiguousarray(a, dtype=np.float32)
             return a, a.ctypes.data, L.CS_MEM_HOST, a.shape[0]
+        if not a.is_contiguous():
+            a = a.contiguous()
+        L.order_after_torch(self._lib.cs_train_wait_stream, self._h, a)    # the batch may still be being gathered on torch's stream
         return a, a.data_ptr(), L.mem_kind(a), a.shape[0]
 
     def step(self, x, y, lr: float = spec.ADAM_LR) -> Tuple[float, float]:
@@ -130,6 +132,9 @@ class Trainer:
         return out
 
     def apply(self, lr: float = spec.ADAM_LR):
+        """Adam update from the gradient buffer.  With use_grad_tensor() that buffer is a torch tensor an all-reduce may
+        still be writing (torch orders its current stream after the collective): the update is ordered after it."""
+        L.order_after_torch(self._lib.cs_train_wait_stream, self._h, self._grad_tensor)
         L.check(self._lib.cs_train_apply(self._h, lr))
 
     def use_grad_tensor(self, t):

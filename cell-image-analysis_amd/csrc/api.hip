@@ -336,7 +336,9 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
     if (cells > m->ws_cells) {
         int rc;
         if ((rc = m->xin.ensure((size_t)cells * m->arch.npix * sizeof(float)))) return rc;
-        for (int l = 0; l < m->arch.n_conv - 1; ++l)
+        // p1 (131 KB per cell, the largest activation) is not materialised when conv1 + conv2 run fused: allocated on demand
+        const bool skip_p1 = m->arch.ref && m->fuse12 && m->use_wino;
+        for (int l = skip_p1 ? 1 : 0; l < m->arch.n_conv - 1; ++l)
             if ((rc = m->act[l].ensure((size_t)cells * m->arch.floats[l] * sizeof(float)))) return rc;
         if ((rc = m->featE.ensure((size_t)cells * m->arch.feat() * sizeof(float)))) return rc;
         if ((rc = m->pca.ensure((size_t)cells * 256 * sizeof(float)))) return rc;
@@ -432,6 +434,10 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         LAUNCH(K_CONV12_FUSED, nc,
                launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
                                    m->act[1].as<float>(), nc, m->stream));
+    if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / A-B knob) needs p1 in HBM
+        int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
+        if (rc) return rc;
+    }
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
@@ -459,6 +465,23 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     }
     return CS_OK;
 }
+
+// An error return from inside a call must not leave a copy from / to the caller's buffers in flight: every compute
+// entry point holds one of these; its destructor drains both streams unless the call reached its normal end
+// (end_call synchronises there itself).
+struct DrainGuard {
+    cs_model* m;
+    bool armed = true;
+    explicit DrainGuard(cs_model* mm) : m(mm) {}
+    ~DrainGuard()
+    {
+        if (armed && m) {
+            if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
+            if (m->stream) (void)hipStreamSynchronize(m->stream);
+        }
+    }
+    int done(int rc) { armed = false; return rc; }
+};
 
 static int begin_call(cs_model* m)
 {
@@ -763,8 +786,9 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;  // improved_detection.py:119-120
+    if (n == 0) return guard.done(CS_OK);  // improved_detection.py:119-120
     if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_screen needs detector parameters");
@@ -839,7 +863,7 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
         if (mod_pred) HIPCHK(hipMemcpyAsync(mod_pred, m->o_pr[1].p, (size_t)n, hipMemcpyDeviceToHost, m->stream));
     }
     if (host_in) HIPCHK(hipStreamSynchronize(m->copy_stream));
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, float* recon, float* mse,
@@ -847,8 +871,9 @@ int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, f
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;
+    if (n == 0) return guard.done(CS_OK);
     if (!crops) return fail(CS_ERR_INVALID, "crops is NULL");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     const int64_t cc = eff_chunk(m, crops_kind);
@@ -873,15 +898,16 @@ int cs_reconstruct(cs_model* m, const float* crops, int64_t n, int crops_kind, f
                                   hipMemcpyDeviceToHost, m->stream));
         if (crops_kind == CS_MEM_HOST || out_kind == CS_MEM_HOST) HIPCHK(hipStreamSynchronize(m->stream));
     }
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_encode(cs_model* m, const float* crops, int64_t n, int crops_kind, int which, float* features, int out_kind)
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;
+    if (n == 0) return guard.done(CS_OK);
     if (!crops || !features) return fail(CS_ERR_INVALID, "crops/features is NULL");
     if (which != 0 && which != 1) return fail(CS_ERR_INVALID, "which must be 0 (autoencoder) or 1 (encoder.keras)");
     if ((rc = check_kind(crops_kind, "crops_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
@@ -899,15 +925,16 @@ int cs_encode(cs_model* m, const float* crops, int64_t n, int crops_kind, int wh
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_layer_output(cs_model* m, const float* crops, int64_t n, int crops_kind, int layer, float* out, int out_kind)
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;
+    if (n == 0) return guard.done(CS_OK);
     if (!crops || !out) return fail(CS_ERR_INVALID, "crops/out is NULL");
     const int last = m->arch.n_conv - 1;
     if (layer < 0 || layer > last) return fail(CS_ERR_INVALID, "layer must be in [0,%d]", last);
@@ -926,15 +953,16 @@ int cs_layer_output(cs_model* m, const float* crops, int64_t n, int crops_kind, 
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, float* pca_out, int out_kind)
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;
+    if (n == 0) return guard.done(CS_OK);
     if (!features || !pca_out) return fail(CS_ERR_INVALID, "features/pca_out is NULL");
     if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_scaler_pca needs detector parameters");
@@ -952,15 +980,16 @@ int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, fl
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
     }
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, double* cons_dec, double* mod_dec, int out_kind)
 {
     int rc = begin_call(m);
     if (rc) return rc;
+    DrainGuard guard(m);
     if (n < 0) return fail(CS_ERR_INVALID, "n is negative");
-    if (n == 0) return CS_OK;
+    if (n == 0) return guard.done(CS_OK);
     if (!pca) return fail(CS_ERR_INVALID, "pca is NULL");
     if ((rc = check_kind(in_kind, "in_kind")) || (rc = check_kind(out_kind, "out_kind"))) return rc;
     if (!m->has_det) return fail(CS_ERR_NO_DETECTOR, "cs_svm_decision needs detector parameters");
@@ -982,7 +1011,7 @@ int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, doubl
         }
         HIPCHK(hipStreamSynchronize(m->stream));
     }
-    return end_call(m);
+    return guard.done(end_call(m));
 }
 
 int cs_synth_crops(cs_model* m, uint64_t seed, int64_t first_cell, int64_t n, int32_t npix, float* out_device)

@@ -69,10 +69,12 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_stats_final_kernel(const float
     for (int g = g0; g < g1; ++g) {
         const float* o = part + (size_t)g * 3 * C;
         const double nb = o[c], mb = o[C + c], M2b = o[2 * C + c];
-        const double tot = n + nb, delta = mb - mu;
-        mu += delta * (nb / tot);
-        M2 += M2b + delta * delta * (n * nb / tot);
-        n = tot;
+        if (nb > 0.0) {                               // an empty partial would make nb / tot = 0 / 0
+            const double tot = n + nb, delta = mb - mu;
+            mu += delta * (nb / tot);
+            M2 += M2b + delta * delta * (n * nb / tot);
+            n = tot;
+        }
     }
     sn[tid] = n; smu[tid] = mu; sM2[tid] = M2;
     __syncthreads();

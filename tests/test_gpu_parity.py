@@ -225,31 +225,40 @@ def test_model_dir_load_and_csv_out(tmp_path, weights, det):
 
 
 def test_full_size_properties(engine, weights, det):
-    """Size-independent properties at a large N (200k cells, device resident):
-    determinism, shard-concatenation equality, and oracle parity on a random sample."""
+    """Size-independent properties at BASELINE.json configs[2]'s full size (1,000,000 cells, device resident, the
+    automatic 65,536-cell pass): determinism, shard-concatenation equality (the multi-GPU partition, section 8e, incl.
+    an uneven 8-way split as configs[3] shards it), and oracle parity on a random sample."""
     import torch
-    n = 200_000
+    from cellscreen import dist as csdist
+    n = 1_000_000
     x = torch.empty((n, 64, 64), dtype=torch.float32, device="cuda")
     engine.synth_crops(42, 0, x)
-    engine.set_chunk(4096)
+    engine.set_chunk(65536)
     r1 = engine.screen(x)
     r2 = engine.screen(x)
     for k in r1:
         assert torch.equal(r1[k], r2[k]), f"{k}: not deterministic"
-    # shards [0, n/2) and [n/2, n) concatenated == whole (the multi-GPU partition, section 8e)
+    # contiguous shards concatenated == whole: 2 halves, and the 8 ranges shard_range gives a 1,000,003-cell job's first 1M
     h = n // 2
     ra, rb = engine.screen(x[:h]), engine.screen(x[h:])
     for k in r1:
         assert torch.equal(torch.cat([ra[k], rb[k]]), r1[k]), f"{k}: shard concat differs"
-    idx = np.sort(np.random.default_rng(0).choice(n, 48, replace=False))
+    parts = [engine.screen(x[lo:hi]) for lo, hi in (csdist.shard_range(n, r, 8) for r in range(8))]
+    for k in r1:
+        assert torch.equal(torch.cat([p[k] for p in parts]), r1[k]), f"{k}: 8-way shard concat differs"
+    idx = np.sort(np.random.default_rng(0).choice(n, 64, replace=False))
     xs = np.stack([oracle.synth_crops(42, int(i), 1)[0] for i in idx])
     assert np.array_equal(x[torch.from_numpy(idx).cuda()].cpu().numpy(), xs)
     ref = oracle.screen(weights, None, det, xs, acc64=True)
     H.assert_rel(r1["mse"].cpu().numpy()[idx], ref["mse"], H.TOL_ERR_REL, "sampled mse")
-    tol = H.TOL_DEC_E2E * np.abs(det.moderate.dual_coef).sum()
-    assert np.abs(r1["mod_score"].cpu().numpy()[idx] - ref["mod_score"]).max() <= tol
+    H.assert_rel(r1["mae"].cpu().numpy()[idx], ref["mae"], H.TOL_ERR_REL, "sampled mae")
+    for name, p in (("cons", det.conservative), ("mod", det.moderate)):
+        tol = H.TOL_DEC_E2E * np.abs(p.dual_coef).sum()
+        assert np.abs(r1[f"{name}_score"].cpu().numpy()[idx] - ref[f"{name}_score"]).max() <= tol
+        H.flags_agree(-r1[f"{name}_score"].cpu().numpy()[idx], r1[f"{name}_pred"].cpu().numpy()[idx], ref[f"{name}_dec"], ref[f"{name}_pred"], tol, name)
     rate = float((r1["cons_pred"] == -1).float().mean())
     assert 0.0 <= rate <= 1.0
+    engine.set_chunk(0)
 
 
 def test_plain_c_program_screens_through_the_abi(tmp_path, weights, det):

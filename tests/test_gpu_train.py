@@ -144,22 +144,34 @@ def test_loss_decreases_and_export_roundtrip():
 
 
 def test_training_class_mirror(tmp_path):
-    """ImprovedAnomalyDetectionTraining: split 80/20 seed 42, callbacks, files, detector, and the
-    resulting model_dir loads in the screening class (CAE_improved_modeltrain.py:480-505 flow)."""
+    """ImprovedAnomalyDetectionTraining with the reference's signatures: split 80/20 seed 42, callbacks, the reference's
+    file set (three `.keras` archives + four pickles, CAE_improved_modeltrain.py:271,299-300,437-444), detector, and the
+    resulting model_dir loads in the screening class (:480-505 flow) -- from the native files and from the six
+    reference files alone."""
+    import shutil
+    from cellscreen import model_io
     from cellscreen.screening import ProductionMutantScreening
     from cellscreen.training import ImprovedAnomalyDetectionTraining
     cells = synth.blob_crops(21, 640)
     out = str(tmp_path / "models")
     t = ImprovedAnomalyDetectionTraining(out, epochs=3, verbose=0)
+    ae0, enc0 = t.create_improved_autoencoder()                                    # (autoencoder, encoder), :184-229
+    assert ae0.n_conv == 7 and enc0.n_conv == 3 and enc0.kernels[0] is ae0.kernels[0]
     autoencoder, encoder, history = t.train_autoencoder(cells)
     h = history.history
     assert len(h["loss"]) == 3 and h["loss"][-1] < h["loss"][0] and len(h["val_loss"]) == 3
     assert encoder.n_conv == 3 and autoencoder.n_conv == 7
-    assert os.path.exists(os.path.join(out, "best_autoencoder", "cae.bin"))
-    assert os.path.exists(os.path.join(out, "final_autoencoder", "cae.bin"))
+    for f in ("best_autoencoder.keras", "final_autoencoder.keras", "encoder.keras"):
+        assert os.path.exists(os.path.join(out, f)), f
+    # Keras 3 restores the best weights at train end: the returned model IS the checkpointed best epoch here
+    best = model_io.cae_from_keras(os.path.join(out, "best_autoencoder.keras"))
+    final = model_io.cae_from_keras(os.path.join(out, "final_autoencoder.keras"))
+    assert all(np.array_equal(a, b) for a, b in zip(final.kernels, autoencoder.kernels))
+    assert history.best_epoch == int(np.argmin(h["val_loss"]))
+    assert all(np.array_equal(a, b) for a, b in zip(best.kernels, final.kernels))
     mse, mae = t.evaluate_reconstruction_quality(autoencoder, cells)
     assert mse.shape == (640,) and mse.dtype == np.float32
-    detectors, scaler, pca = t.create_anomaly_detector(encoder, cells, autoencoder=autoencoder)
+    detectors, scaler, pca = t.create_anomaly_detector(encoder, cells)             # the reference's two-argument call, :394
     assert set(detectors) == {"Conservative", "Moderate"} and pca.n_components_ == 100
     for f in ("scaler.pkl", "pca.pkl", "detector_conservative.pkl", "detector_moderate.pkl", "cae.bin", "detector.bin"):
         assert os.path.exists(os.path.join(out, f)), f
@@ -170,20 +182,52 @@ def test_training_class_mirror(tmp_path):
     dec = detectors["Conservative"].decision_function(pca.transform(scaler.transform(feats.copy())))
     assert np.abs(-r["conservative_scores"] - dec).max() <= 1e-4 * np.abs(detectors["Conservative"].dual_coef_).sum()
     assert 0.0 <= r["conservative_anomaly_rate"] <= 0.5
+    # the reference's six files alone (improved_detection.py:28-41) are a loadable model_dir: same scores, bit for bit
+    six = tmp_path / "six"
+    six.mkdir()
+    for f in ("best_autoencoder.keras", "encoder.keras", "scaler.pkl", "pca.pkl", "detector_conservative.pkl", "detector_moderate.pkl"):
+        shutil.copy(os.path.join(out, f), six / f)
+    s2 = ProductionMutantScreening(str(six))
+    r2 = s2.compute_anomaly_scores(list(cells[:50]))
+    for k in ("reconstruction_mse", "conservative_scores", "moderate_scores", "conservative_predictions"):
+        assert np.array_equal(r[k], r2[k]), k
 
 
 def test_training_with_the_reference_augmentation(tmp_path):
-    """augment="reference": the generator of CAE_improved_modeltrain.py:246-254 on the GPU, input only (:287)."""
+    """The default augment="reference": the generator of CAE_improved_modeltrain.py:246-254 on the GPU, input only (:287);
+    augment=None is the opt-out."""
     from cellscreen.training import ImprovedAnomalyDetectionTraining
     cells = synth.blob_crops(22, 320)
-    t = ImprovedAnomalyDetectionTraining(str(tmp_path / "aug"), epochs=3, verbose=0, augment="reference")
+    t = ImprovedAnomalyDetectionTraining(str(tmp_path / "aug"), epochs=3, verbose=0)
+    assert t.augment == "reference"
     _, _, history = t.train_autoencoder(cells)
     h = history.history
     assert len(h["loss"]) == 3 and np.isfinite(h["loss"]).all() and h["loss"][-1] < h["loss"][0]
-    assert callable(t.augment)                              # the hook was bound to the trainer's generator
-    t2 = ImprovedAnomalyDetectionTraining(str(tmp_path / "plain"), epochs=3, verbose=0)
+    t2 = ImprovedAnomalyDetectionTraining(str(tmp_path / "plain"), epochs=3, verbose=0, augment=None)
     _, _, h2 = t2.train_autoencoder(cells)
     assert h2.history["loss"] != h["loss"]                  # the augmented run really saw different inputs
+
+
+def test_device_inputs_are_ordered_after_torch_work():
+    """The handles work on their own non-blocking streams; the wrappers order them after torch's current stream
+    (cs_*_wait_stream) instead of relying on the caller to synchronise.  Feed the output of a long chain of async
+    torch kernels straight in: the library must see the finished tensor."""
+    import torch
+    from cellscreen.engine import Engine
+    w = synth.random_cae(seed=42)
+    e = Engine.from_weights(w)
+    base = torch.from_numpy(synth.synth_crops(5, 0, 4096)).cuda()
+    want = e.layer_output(base, 1).clone()
+    torch.cuda.synchronize()
+    for trial in range(5):
+        x = torch.zeros_like(base)
+        big = torch.randn(4096, 4096, device="cuda")
+        for _ in range(20):                                 # keep torch's stream busy for milliseconds
+            big = big @ big * 1e-3
+        x += base * (1.0 + 0.0 * big[0, 0])                 # x is final only when the chain above has run
+        got = e.layer_output(x, 1)
+        assert torch.equal(got, want), f"trial {trial}: the library read the tensor before torch finished writing it"
+    e.close()
 
 
 import os  # noqa: E402

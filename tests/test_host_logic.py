@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"libcellscreen.so does not export {n}"
     assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES out of sync with include/cellscreen.h"
     assert lib.cs_abi_version() == 1
-    assert lib.cs_profile_kernel_count() == 12
+    assert lib.cs_profile_kernel_count() == 13 and lib.cs_profile_kernel_name(12) == b"conv1_conv2_fused"
     assert lib.cs_profile_kernel_name(1) == b"conv2_relu_bn_pool"
     assert lib.cs_status_string(-4) == b"no usable gfx950 device"
 
