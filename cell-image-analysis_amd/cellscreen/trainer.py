@@ -53,14 +53,15 @@ def flat_from_weights(w: CAEWeights) -> Tuple[np.ndarray, np.ndarray]:
     return np.concatenate(p).astype(np.float32), np.concatenate(m).astype(np.float32)
 
 
-def weights_from_flat(params: np.ndarray, moving: np.ndarray, bn_eps=spec.BN_EPS) -> CAEWeights:
-    p = split_flat(params, param_layout())
-    m = split_flat(moving, moving_layout())
-    n = len(spec.CHANNELS)
+def weights_from_flat(params: np.ndarray, moving: np.ndarray, bn_eps=spec.BN_EPS, channels=spec.CHANNELS,
+                      input_hw=spec.INPUT_HW, n_enc=spec.N_ENC) -> CAEWeights:
+    p = split_flat(params, param_layout(channels))
+    m = split_flat(moving, moving_layout(channels))
+    n = len(channels)
     return CAEWeights([p[f"conv{l}.kernel"] for l in range(n)], [p[f"conv{l}.bias"] for l in range(n)],
                       [p[f"bn{l}.gamma"] for l in range(n - 1)], [p[f"bn{l}.beta"] for l in range(n - 1)],
                       [m[f"bn{l}.mean"] for l in range(n - 1)], [m[f"bn{l}.var"] for l in range(n - 1)],
-                      bn_eps=bn_eps).validate()
+                      tuple(input_hw), n_enc, bn_eps).validate()
 
 
 class Trainer:
@@ -74,9 +75,12 @@ class Trainer:
         L.check(self._lib.cs_train_create(C.byref(w), C.byref(cfg), device_id, C.byref(h)))
         self._h = h
         self.bn_eps = init.bn_eps
+        # the architecture: the reference graph, or any other instance of its layer grammar (csrc/train_generic.hip)
+        self.channels, self.input_hw, self.n_enc = tuple(init.channels), tuple(init.input_hw), init.n_enc
         nt, nm = C.c_int64(), C.c_int64()
-        L.check(self._lib.cs_train_param_count(C.byref(nt), C.byref(nm)))
+        L.check(self._lib.cs_train_param_count_of(self._h, C.byref(nt), C.byref(nm)))
         self.n_trainable, self.n_moving = nt.value, nm.value
+        assert self.n_trainable == sum(int(np.prod(s)) for _, s in param_layout(self.channels))
         self._grad_tensor = None
 
     def close(self):
@@ -154,9 +158,9 @@ class Trainer:
 
     def tensor(self, which: int, layer: int, batch: int) -> np.ndarray:
         """Stage tap (parity tests): which 0 relu out, 1 BN out, 2 dz, 3 dBN-out, 4 sigmoid out."""
-        rows = spec.layer_table()
-        if which == 4 or (which == 2 and layer == 6):
-            shape = (batch, 64, 64)
+        rows = spec.layer_table(self.input_hw, self.channels, self.n_enc)
+        if which == 4 or (which == 2 and layer == len(self.channels) - 1):
+            shape = (batch,) + self.input_hw
         elif which in (0, 2):
             shape = (batch,) + rows[layer]["conv_hw"] + (rows[layer]["cout"],)
         else:
@@ -174,7 +178,7 @@ class Trainer:
 
     def weights(self) -> CAEWeights:
         p, m = self.export_flat()
-        return weights_from_flat(p, m, self.bn_eps)
+        return weights_from_flat(p, m, self.bn_eps, self.channels, self.input_hw, self.n_enc)
 
     def load_flat(self, params: Optional[np.ndarray], moving: Optional[np.ndarray]):
         pp = np.ascontiguousarray(params, np.float32) if params is not None else None

@@ -759,7 +759,7 @@ int cs_model_get_info(const cs_model* m, cs_model_info* info)
 
 int cs_model_set_chunk(cs_model* m, int64_t chunk_cells)
 {
-    if (!m || chunk_cells <= 0 || chunk_cells > (1 << 20)) return fail(CS_ERR_INVALID, "chunk_cells must be in [1, 2^20]");
+    if (!m || chunk_cells < 0 || chunk_cells > (1 << 20)) return fail(CS_ERR_INVALID, "chunk_cells must be in [0, 2^20] (0 = automatic)");
     m->chunk = chunk_cells;
     return CS_OK;
 }

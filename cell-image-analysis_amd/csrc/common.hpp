@@ -95,10 +95,17 @@ hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
                        hipStream_t s);
 // run-time-shaped conv for non-reference architectures (conv_generic.hip)
-enum { GEN_EPI_BN = 0, GEN_EPI_BN_POOL = 1, GEN_EPI_SIGMOID = 2 };
+// GEN_EPI_RELU (bias -> ReLU, full resolution) and GEN_EPI_PLAIN (the raw sums; ep may be NULL) serve training:
+// forward with BatchNormalization in batch mode, and the backward-data convs (train_generic.hip)
+enum { GEN_EPI_BN = 0, GEN_EPI_BN_POOL = 1, GEN_EPI_SIGMOID = 2, GEN_EPI_RELU = 3, GEN_EPI_PLAIN = 4 };
 int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t why_len);
 hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float* ep, float* out, int64_t n, int H, int W, int cin,
                                int cout, int ups, int epi, hipStream_t stream);
+// run-time-shaped training kernels (train_generic.hip)
+hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s);
+hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int W, int C, hipStream_t s);
+hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, int64_t n, int H, int W, int cin, int cout, int ups,
+                                int max_parts, int* nparts, hipStream_t s);
 hipError_t launch_recon_err(const float* recon, const float* x, int64_t n, int npix, float* errpart, hipStream_t stream);
 // training augmentation: affine bilinear resample (nearest fill) + flips, one image per workgroup
 hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s);

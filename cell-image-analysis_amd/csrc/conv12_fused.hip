@@ -110,7 +110,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
     float* const inp = (float*)(smem + OFF_INP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, kq = lane >> 4;
 
     // ---- P3 operands: U of this wave's 18 transform points, all 32 input channels, its 16 filters.  These 144 VGPRs
     // are the kernel's register budget; every other per-lane constant is kept in LDS or recomputed per group.

@@ -160,8 +160,20 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
             }
             // D: lane = channel li of the slice, registers = pixels 4 kq .. 4 kq + 3 of the tile
             if (co < cout) {
-                const float bias = g.ep[co];
-                if (g.epi == GEN_EPI_SIGMOID) {
+                const float bias = g.epi == GEN_EPI_PLAIN ? 0.0f : g.ep[co];
+                if (g.epi == GEN_EPI_RELU || g.epi == GEN_EPI_PLAIN) {
+                    const bool relu = g.epi == GEN_EPI_RELU;
+                    float* o = g.out + ((size_t)cell * H + y0) * W * cout;
+#pragma unroll
+                    for (int t = 0; t < TPS; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (!mine(t)) continue;
+                            const int py = t / TPR, px = (t % TPR) * 16 + 4 * kq + r;
+                            const float z = acc[t][r] + bias;
+                            o[((size_t)py * W + px) * cout + co] = relu ? fmaxf(z, 0.0f) : z;
+                        }
+                } else if (g.epi == GEN_EPI_SIGMOID) {
                     float* o = g.out + ((size_t)cell * H + y0) * W * cout;
 #pragma unroll
                     for (int t = 0; t < TPS; ++t)

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
                                                                float* __restrict__ part /*[G][3][C]*/)
 {
     __shared__ float red[256];
-    __shared__ float meanc[64];
+    __shared__ float meanc[256];
     const int tid = threadIdx.x;
     const int c = tid % C, lane = tid / C, L = 256 / C;
     const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const float* __restrict__ r, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats /*[2][C]*/, float* __restrict__ a, long N, int H, int W, int pool)
 {
-    __shared__ float sm[64], si[64], sg[64], sb[64];
+    __shared__ float sm[256], si[256], sg[256], sb[256];
     const int tid = threadIdx.x;
     if (tid < C) { sm[tid] = stats[tid]; si[tid] = stats[C + tid]; sg[tid] = gamma[tid]; sb[tid] = beta[tid]; }
     __syncthreads();

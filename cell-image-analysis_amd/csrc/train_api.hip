@@ -4,42 +4,15 @@
 // backward, Keras Adam -- plus the inference-mode evaluation used for val_loss.
 // Callbacks (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, :263-283) are host-side
 // scalars and live in cellscreen/training.py.
-#include "api_internal.hpp"
+#include "train_internal.hpp"
 
 #include <cmath>
 
 using namespace cs;
 
-struct cs_trainer {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    cs_train_cfg cfg;
-    int64_t maxb = 0;
-    // flat parameter layout, Keras order: conv l kernel (HWIO), bias, [gamma, beta]
-    long off_k[7], off_b[7], off_g[6], off_be[6], nparam = 0;
-    long off_mm[6], off_mv[6], nmov = 0;
-    DevBuf P, Gown, M, V, MOV;
-    float* G = nullptr;                 // gradient buffer in use (own or caller's)
-    long step = 0;
-    // packed operands, rebuilt after every update
-    DevBuf wf[6], wft[7], w7eff, ep_inf[6];
-    // batch tensors
-    DevBuf x, y, r[6], a[6], out, errpart, dz[7], da[6], stats[6];
-    DevBuf aug_tf, aug_in, aug_out;
-    DevBuf part_stats, part_bwd, bwd_sums, dzsum_part[7], wpart[7], descs, scal;
-    int np_w[7], np_b[7];
-    ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
-};
-
 static int cin_of(int l) { return l == 0 ? 1 : kRefChannels[l - 1]; }
 static size_t a_floats(int l) { return kLayerFloats[l]; }                                   // stored BN output per cell
 static size_t r_floats(int l) { return (size_t)kConvGrid[l] * kConvGrid[l] * kRefChannels[l]; }  // conv-grid tensor per cell
-
-#define LCHK(call)                                                                             \
-    do {                                                                                       \
-        hipError_t le__ = (call);                                                              \
-        if (le__ != hipSuccess) return fail(CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(le__)); \
-    } while (0)
 
 static int repack(cs_trainer* t)
 {
@@ -84,41 +57,88 @@ int cs_train_param_count(int64_t* n_trainable, int64_t* n_moving)
     return CS_OK;
 }
 
+// Describes the architecture of `init`; non-reference instances must follow the layer grammar and fit the run-time-shaped
+// kernels in both directions (the backward-data conv of layer l has cin' = filters(l), cout' = cin(l)).
+static int describe_trainer(cs_trainer* t, const cs_cae_weights* w)
+{
+    if (!w) return fail(CS_ERR_INVALID, "initial weights are NULL");
+    t->H = w->height; t->W = w->width; t->n_conv = w->n_conv; t->n_enc = w->n_enc;
+    if (t->n_conv < 3 || t->n_conv > TR_MAXL || t->n_enc < 1 || t->n_conv != 2 * t->n_enc + 1)
+        return fail(CS_ERR_UNSUPPORTED, "initial weights: n_conv=%d n_enc=%d is not the reference grammar (n_conv = 2 n_enc + 1)", t->n_conv, t->n_enc);
+    if (t->H <= 0 || t->W <= 0 || t->H % (1 << t->n_enc) || t->W % (1 << t->n_enc))
+        return fail(CS_ERR_UNSUPPORTED, "initial weights: input %dx%d is not divisible by 2^n_enc", t->H, t->W);
+    t->ref = t->H == kH && t->W == kW && t->n_conv == kNConv && t->n_enc == kNEnc;
+    int h = t->H, wd = t->W;
+    for (int l = 0; l < t->n_conv; ++l) {
+        t->ch[l] = w->channels[l];
+        if (t->ch[l] <= 0) return fail(CS_ERR_INVALID, "initial weights: conv %d has %d filters", l, t->ch[l]);
+        if (t->ref && t->ch[l] != kRefChannels[l]) t->ref = false;
+        if (!w->kernel[l] || !w->bias[l]) return fail(CS_ERR_INVALID, "initial weights: conv %d kernel/bias is NULL", l);
+        if (l < t->n_conv - 1 && (!w->bn_gamma[l] || !w->bn_beta[l] || !w->bn_mean[l] || !w->bn_var[l]))
+            return fail(CS_ERR_INVALID, "initial weights: conv %d BatchNormalization arrays are NULL", l);
+        if (l > t->n_enc) { h *= 2; wd *= 2; }
+        t->gh[l] = h; t->gw[l] = wd;
+        t->rfl[l] = (size_t)h * wd * t->ch[l];
+        if (l < t->n_enc) { h /= 2; wd /= 2; }
+        t->afl[l] = (size_t)h * wd * t->ch[l];
+    }
+    if (t->ch[t->n_conv - 1] != 1) return fail(CS_ERR_UNSUPPORTED, "initial weights: the last conv must have 1 filter");
+    if (!t->ref) {
+        char why[160];
+        for (int l = 0; l < t->n_conv; ++l) {
+            if (!conv_generic_supported(t->gh[l], t->gw[l], t->cin(l), t->ch[l], why, sizeof why))
+                return fail(CS_ERR_UNSUPPORTED, "training, conv %d: %s", l, why);
+            if (l > 0 && !conv_generic_supported(t->gh[l], t->gw[l], t->ch[l], t->cin(l), why, sizeof why))
+                return fail(CS_ERR_UNSUPPORTED, "training, backward-data conv %d: %s", l, why);
+        }
+    }
+    return CS_OK;
+}
+
+int cs_train_param_count_of(const cs_trainer* t, int64_t* n_trainable, int64_t* n_moving)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (n_trainable) *n_trainable = t->nparam;
+    if (n_moving) *n_moving = t->nmov;
+    return CS_OK;
+}
+
 int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int device_id, cs_trainer** out)
 {
     if (!out) return fail(CS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!cfg) return fail(CS_ERR_INVALID, "cfg is NULL");
-    int rc = check_arch(init, kNConv, "initial weights");
-    if (rc) return rc;
+    int rc;
     if ((rc = require_gfx950(device_id))) return rc;
     cs_trainer* t = new (std::nothrow) cs_trainer();
     if (!t) return fail(CS_ERR_NOMEM, "host allocation failed");
     t->device = device_id;
     t->cfg = *cfg;
 #define TFAIL(x) do { int r__ = (x); if (r__) { delete t; return r__; } } while (0)
+    TFAIL(describe_trainer(t, init));
     {
         hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete t; return fail(CS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     }
+    const int NL = t->n_conv;
     long o = 0, mo = 0;
-    for (int l = 0; l < 7; ++l) {
-        t->off_k[l] = o; o += 9L * cin_of(l) * kRefChannels[l];
-        t->off_b[l] = o; o += kRefChannels[l];
-        if (l < 6) {
-            t->off_g[l] = o; o += kRefChannels[l];
-            t->off_be[l] = o; o += kRefChannels[l];
-            t->off_mm[l] = mo; mo += kRefChannels[l];
-            t->off_mv[l] = mo; mo += kRefChannels[l];
+    for (int l = 0; l < NL; ++l) {
+        t->off_k[l] = o; o += 9L * t->cin(l) * t->ch[l];
+        t->off_b[l] = o; o += t->ch[l];
+        if (l < NL - 1) {
+            t->off_g[l] = o; o += t->ch[l];
+            t->off_be[l] = o; o += t->ch[l];
+            t->off_mm[l] = mo; mo += t->ch[l];
+            t->off_mv[l] = mo; mo += t->ch[l];
         }
     }
     t->nparam = o; t->nmov = mo;
     std::vector<float> hp(o), hm(mo);
-    for (int l = 0; l < 7; ++l) {
-        const int c = kRefChannels[l];
-        memcpy(&hp[t->off_k[l]], init->kernel[l], sizeof(float) * 9 * cin_of(l) * c);
+    for (int l = 0; l < NL; ++l) {
+        const int c = t->ch[l];
+        memcpy(&hp[t->off_k[l]], init->kernel[l], sizeof(float) * 9 * t->cin(l) * c);
         memcpy(&hp[t->off_b[l]], init->bias[l], sizeof(float) * c);
-        if (l < 6) {
+        if (l < NL - 1) {
             memcpy(&hp[t->off_g[l]], init->bn_gamma[l], sizeof(float) * c);
             memcpy(&hp[t->off_be[l]], init->bn_beta[l], sizeof(float) * c);
             memcpy(&hm[t->off_mm[l]], init->bn_mean[l], sizeof(float) * c);
@@ -132,6 +152,13 @@ int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int dev
     {
         hipError_t e1 = hipMemset(t->M.p, 0, o * 4), e2 = hipMemset(t->V.p, 0, o * 4), e3 = hipMemset(t->Gown.p, 0, o * 4);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { delete t; return fail(CS_ERR_HIP, "hipMemset failed"); }
+    }
+    if (!t->ref) {
+        TFAIL(gen_train_setup(t));
+        hipError_t e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) { delete t; return fail(CS_ERR_HIP, "initial repack: %s", hipGetErrorString(e)); }
+        *out = t;
+        return CS_OK;
     }
     for (int l = 0; l < 6; ++l) {
         TFAIL(t->wf[l].ensure(pack_conv_fragments(cin_of(l), kRefChannels[l], nullptr, nullptr) * 4));
@@ -194,6 +221,7 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
     if (!x || !y || batch <= 0) return fail(CS_ERR_INVALID, "x/y NULL or batch <= 0");
     if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
     HIPCHK(hipSetDevice(t->device));
+    if (!t->ref) return gen_train_forward_backward(t, x, y, batch, kind, loss, mae);
     int rc = ensure_batch(t, batch);
     if (rc) return rc;
     const int64_t B = batch;
@@ -267,7 +295,7 @@ int cs_train_apply(cs_trainer* t, float lr)
     const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
     LCHK(launch_adam(t->P.as<float>(), t->G, t->M.as<float>(), t->V.as<float>(), t->nparam, alpha, t->cfg.beta1,
                      t->cfg.beta2, t->cfg.adam_eps, t->stream));
-    int rc = repack(t);
+    int rc = t->ref ? repack(t) : gen_train_repack(t);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(t->stream));
     return CS_OK;
@@ -286,6 +314,7 @@ int cs_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int 
     if (!x || !y || n <= 0) return fail(CS_ERR_INVALID, "x/y NULL or n <= 0");
     if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
     HIPCHK(hipSetDevice(t->device));
+    if (!t->ref) return gen_train_eval(t, x, y, n, kind, loss, mae);
     const int64_t ch = n < 4096 ? n : 4096;
     int rc = ensure_batch(t, ch);
     if (rc) return rc;
@@ -327,7 +356,7 @@ int cs_train_augment(cs_trainer* t, const float* x, int64_t n, const cs_aug_affi
     if (x == out) return fail(CS_ERR_INVALID, "out aliases x");
     if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
     HIPCHK(hipSetDevice(t->device));
-    const size_t bytes = (size_t)n * kH * kW * sizeof(float);
+    const size_t bytes = (size_t)n * t->H * t->W * sizeof(float);
     int rc;
     if ((rc = t->aug_tf.ensure((size_t)n * sizeof(cs_aug_affine)))) return rc;
     HIPCHK(hipMemcpyAsync(t->aug_tf.p, tf, (size_t)n * sizeof(cs_aug_affine), hipMemcpyHostToDevice, t->stream));
@@ -339,7 +368,7 @@ int cs_train_augment(cs_trainer* t, const float* x, int64_t n, const cs_aug_affi
         d_in = t->aug_in.as<float>();
         d_out = t->aug_out.as<float>();
     }
-    LCHK(launch_augment(d_in, t->aug_tf.as<cs_aug_affine>(), d_out, n, kH, kW, t->stream));
+    LCHK(launch_augment(d_in, t->aug_tf.as<cs_aug_affine>(), d_out, n, t->H, t->W, t->stream));
     if (kind == CS_MEM_HOST) HIPCHK(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return CS_OK;
@@ -359,16 +388,18 @@ int cs_train_export(cs_trainer* t, float* params_host, float* moving_host, float
 int cs_train_tensor(cs_trainer* t, int which, int layer, int64_t batch, float* host)
 {
     if (!t || !host) return fail(CS_ERR_INVALID, "NULL argument");
-    if (layer < 0 || layer > 6 || batch <= 0 || batch > t->maxb) return fail(CS_ERR_INVALID, "bad layer/batch");
+    const int last = t->n_conv - 1;
+    if (layer < 0 || layer > last || batch <= 0 || batch > t->maxb) return fail(CS_ERR_INVALID, "bad layer/batch");
     HIPCHK(hipSetDevice(t->device));
     const DevBuf* b = nullptr;
     size_t per = 0;
+    const size_t npix = (size_t)t->H * t->W;
     switch (which) {
-        case 0: if (layer < 6) { b = &t->r[layer]; per = r_floats(layer); } break;    // relu(conv) output
-        case 1: if (layer < 6) { b = &t->a[layer]; per = a_floats(layer); } break;    // BN (+pool) output
-        case 2: b = &t->dz[layer]; per = layer < 6 ? r_floats(layer) : (size_t)kH * kW; break;   // dL/dz
-        case 3: if (layer < 6) { b = &t->da[layer]; per = a_floats(layer); } break;   // dL/d(BN output)
-        case 4: b = &t->out; per = (size_t)kH * kW; break;                             // sigmoid output
+        case 0: if (layer < last) { b = &t->r[layer]; per = t->rfl[layer]; } break;    // relu(conv) output
+        case 1: if (layer < last) { b = &t->a[layer]; per = t->afl[layer]; } break;    // BN (+pool) output
+        case 2: b = &t->dz[layer]; per = layer < last ? t->rfl[layer] : npix; break;   // dL/dz
+        case 3: if (layer < last) { b = &t->da[layer]; per = t->afl[layer]; } break;   // dL/d(BN output)
+        case 4: b = &t->out; per = npix; break;                                         // sigmoid output
         default: break;
     }
     if (!b) return fail(CS_ERR_INVALID, "no such tensor");
@@ -383,7 +414,7 @@ int cs_train_import(cs_trainer* t, const float* params_host, const float* moving
     HIPCHK(hipSetDevice(t->device));
     if (params_host) HIPCHK(hipMemcpy(t->P.p, params_host, t->nparam * 4, hipMemcpyHostToDevice));
     if (moving_host) HIPCHK(hipMemcpy(t->MOV.p, moving_host, t->nmov * 4, hipMemcpyHostToDevice));
-    int rc = repack(t);
+    int rc = t->ref ? repack(t) : gen_train_repack(t);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(t->stream));
     return CS_OK;

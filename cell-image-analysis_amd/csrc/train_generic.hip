@@ -1,0 +1,321 @@
+// train_generic.hip -- one `autoencoder.fit` step (CAE_improved_modeltrain.py:223-227, 286-293) for ANY instance of the
+// reference's layer grammar (create_improved_autoencoder(input_shape) is generic, :184; BASELINE.json configs[4]: 128x128
+// crops, filters 32-64-128 | 128-64-32-1), on run-time-shaped kernels:
+//   forward        conv_generic.hip in GEN_EPI_RELU mode (bias -> ReLU at full resolution), the BatchNormalization /
+//                  max-pool kernels of train.hip (they take N, H, W, C at run time), sigmoid conv + error sums
+//   backward-data  the same generic conv with the kernel flipped and its channel roles swapped (GEN_EPI_PLAIN);
+//                  through an UpSampling2D the adjoint is a 2x2 sum
+//   weight grads   an MFMA GEMM per tap: dW[tap][ci][co] = sum over pixels of in[pixel + tap][ci] * dz[pixel][co]
+//                  (M = 16 input channels, N = 16 filters, K = pixels), per-workgroup partials in a fixed order
+//   reduction, Adam: train.hip (flat parameter vector, no float atomics: bit-reproducible run to run)
+// The reference graph never takes this path (train_api.hip runs it on the tuned kernels); this one is shape-free and
+// correct first -- the 128x128 variant's gradient all-reduce (same flat-gradient split as the reference graph:
+// cs_train_forward_backward -> all-reduce -> cs_train_apply) is what BASELINE.json configs[4] needs from it.
+#include "train_internal.hpp"
+
+#include <vector>
+
+using namespace cs;
+
+namespace cs {
+namespace {
+
+__global__ void flip_transpose_kernel(const float* __restrict__ w, int cin, int cout, float* __restrict__ dst)
+{
+    const long total = 9L * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout);
+        const int ci = (int)((i / cout) % cin);
+        const int tap = (int)(i / ((long)cout * cin));
+        dst[((long)(8 - tap) * cout + co) * cin + ci] = w[i];       // (2-dy, 2-dx) = tap 8 - tap; channel roles swapped
+    }
+}
+
+__global__ void sumpool2x2_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int H, int W, int C)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = n * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int x = (int)(p % Wo), y = (int)((p / Wo) % Ho);
+        const long cell = p / ((long)Wo * Ho);
+        const float* s = in + (((cell * H + 2 * y) * W + 2 * x) * C + c);
+        out[i] = (s[0] + s[C]) + (s[(long)W * C] + s[(long)W * C + C]);
+    }
+}
+
+// Weight gradient of one conv: part[p][tap][ci][co] for the pixels of part p.  A wave owns one 16 x 16 (ci, co) tile
+// for all nine taps (nine accumulators): per 4 consecutive pixels of a conv row one B load (dz) feeds nine MFMAs.
+struct WgArgs {
+    const float* xin;    // stored input [n][Hs][Ws][cin]  (Hs = H/2 when ups)
+    const float* dz;     // [n][H][W][cout]
+    float* part;         // [nparts][9][cin][cout]
+    long n;
+    int H, W, cin, cout, ups, tm, tn, nparts;
+};
+
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tiles = g.tm * g.tn, wg_per_part = (tiles + 3) / 4;
+    const int p = blockIdx.x / wg_per_part, tile = (blockIdx.x % wg_per_part) * 4 + wave;
+    if (tile >= tiles) return;
+    const int cib = tile / g.tn, cob = tile % g.tn;
+    const int ci = cib * 16 + li, co = cob * 16 + li;
+    const int H = g.H, W = g.W, Ws = g.ups ? W / 2 : W, Hs = g.ups ? H / 2 : H;
+    const long groups = g.n * H * (W / 4);                 // groups of 4 consecutive pixels of a row
+    const long g0 = (groups * p) / g.nparts, g1 = (groups * (p + 1)) / g.nparts;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (long q = g0; q < g1; ++q) {
+        const int x = (int)(q % (W / 4)) * 4 + kq;
+        const long row = q / (W / 4);
+        const int y = (int)(row % H);
+        const long cell = row / H;
+        const float b = co < g.cout ? g.dz[((cell * H + y) * W + x) * g.cout + co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            float a = 0.0f;
+            if (ci < g.cin && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const int sy = g.ups ? yy >> 1 : yy, sx = g.ups ? xx >> 1 : xx;
+                a = g.xin[((cell * Hs + sy) * Ws + sx) * g.cin + ci];
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // D: lane = filter li of the tile, registers = input channels 4 kq .. 4 kq + 3
+    if (co < g.cout) {
+        float* o = g.part + (size_t)p * 9 * g.cin * g.cout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c2 = cib * 16 + 4 * kq + r;
+                if (c2 < g.cin) o[((size_t)t * g.cin + c2) * g.cout + co] = acc[t][r];
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s)
+{
+    const long total = 9L * cin * cout;
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hwio, cin, cout, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int W, int C, hipStream_t s)
+{
+    const long total = (long)n * (H / 2) * (W / 2) * C;
+    long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)grid), dim3(256), 0, s, in, out, (long)n, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, int64_t n, int H, int W, int cin, int cout, int ups,
+                                int max_parts, int* nparts, hipStream_t s)
+{
+    WgArgs g;
+    g.xin = xin; g.dz = dz; g.part = part; g.n = n; g.H = H; g.W = W; g.cin = cin; g.cout = cout; g.ups = ups;
+    g.tm = (cin + 15) / 16; g.tn = (cout + 15) / 16;
+    const int wg_per_part = (g.tm * g.tn + 3) / 4;
+    const long groups = (long)n * H * (W / 4);
+    long np = 2048 / wg_per_part;
+    if (np > max_parts) np = max_parts;
+    if (np > groups) np = groups;
+    if (np < 1) np = 1;
+    g.nparts = (int)np;
+    *nparts = g.nparts;
+    hipLaunchKernelGGL(wgrad_generic_kernel, dim3((unsigned)(g.nparts * wg_per_part)), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace cs
+
+// ------------------------------------------------------------------------------------------------ orchestration
+static int gen_parts(const cs_trainer* t, int l)
+{
+    const int wg_per_part = (((t->cin(l) + 15) / 16) * ((t->ch[l] + 15) / 16) + 3) / 4;
+    long np = 2048 / wg_per_part;
+    if (np > TRAIN_MAX_PARTS) np = TRAIN_MAX_PARTS;
+    return np < 1 ? 1 : (int)np;
+}
+
+int gen_train_setup(cs_trainer* t)
+{
+    int rc;
+    int cmax = 1;
+    for (int l = 0; l < t->n_conv; ++l) cmax = t->ch[l] > cmax ? t->ch[l] : cmax;
+    for (int l = 0; l < t->n_conv - 1; ++l) {
+        if (256 % t->ch[l]) return fail(CS_ERR_UNSUPPORTED, "training: conv %d has %d filters; the BatchNormalization kernels need a divisor of 256", l, t->ch[l]);
+        if ((rc = t->ep_inf[l].ensure(3 * (size_t)t->ch[l] * 4)) || (rc = t->stats[l].ensure(2 * (size_t)t->ch[l] * 4))) return rc;
+    }
+    for (int l = 1; l < t->n_conv; ++l)
+        if ((rc = t->wft[l].ensure(9 * (size_t)t->cin(l) * t->ch[l] * 4))) return rc;
+    if ((rc = t->part_stats.ensure((size_t)BN_MAX_PARTS * 3 * cmax * 4)) || (rc = t->part_bwd.ensure((size_t)BN_MAX_PARTS * 2 * cmax * 4)) ||
+        (rc = t->bwd_sums.ensure(2 * (size_t)cmax * 4)))
+        return rc;
+    for (int l = 0; l < t->n_conv; ++l) {
+        if ((rc = t->dzsum_part[l].ensure((size_t)BN_MAX_PARTS * cmax * 4))) return rc;
+        if ((rc = t->wpart[l].ensure((size_t)gen_parts(t, l) * 9 * t->cin(l) * t->ch[l] * 4))) return rc;
+    }
+    if ((rc = t->descs.ensure(2 * TR_MAXL * sizeof(ReduceDesc))) || (rc = t->scal.ensure(16))) return rc;
+    return gen_train_repack(t);
+}
+
+int gen_train_repack(cs_trainer* t)
+{
+    float* P = t->P.as<float>();
+    for (int l = 1; l < t->n_conv; ++l)
+        LCHK(launch_flip_transpose(P + t->off_k[l], t->cin(l), t->ch[l], t->wft[l].as<float>(), t->stream));
+    return CS_OK;
+}
+
+int gen_train_ensure_batch(cs_trainer* t, int64_t b)
+{
+    if (b <= t->maxb) return CS_OK;
+    int rc;
+    const size_t npix = (size_t)t->H * t->W;
+    if ((rc = t->x.ensure(b * npix * 4)) || (rc = t->y.ensure(b * npix * 4))) return rc;
+    size_t dup = 0;
+    const int last = t->n_conv - 1;
+    for (int l = 0; l < last; ++l) {
+        if ((rc = t->r[l].ensure(b * t->rfl[l] * 4)) || (rc = t->a[l].ensure(b * t->afl[l] * 4)) || (rc = t->da[l].ensure(b * t->afl[l] * 4)) ||
+            (rc = t->dz[l].ensure(b * t->rfl[l] * 4)))
+            return rc;
+    }
+    for (int l = t->n_enc + 1; l < t->n_conv; ++l) {          // upsample-fed convs: gradient wrt the upsampled input, before the 2x2 sum
+        const size_t f = (size_t)t->gh[l] * t->gw[l] * t->cin(l);
+        dup = f > dup ? f : dup;
+    }
+    if ((rc = t->dup.ensure(b * dup * 4))) return rc;
+    if ((rc = t->dz[last].ensure(b * npix * 4)) || (rc = t->out.ensure(b * npix * 4)) || (rc = t->errpart.ensure((size_t)b * 8 * 4))) return rc;
+    t->maxb = b;
+    return CS_OK;
+}
+
+static int gen_copy_in(cs_trainer* t, DevBuf& dst, const float* src, int kind, size_t floats)
+{
+    HIPCHK(hipMemcpyAsync(dst.p, src, floats * 4, kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, t->stream));
+    return CS_OK;
+}
+
+int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae)
+{
+    int rc = gen_train_ensure_batch(t, batch);
+    if (rc) return rc;
+    const int64_t B = batch;
+    hipStream_t s = t->stream;
+    float* P = t->P.as<float>();
+    float* G = t->G;
+    float* MOV = t->MOV.as<float>();
+    const int last = t->n_conv - 1;
+    const size_t npix = (size_t)t->H * t->W;
+    if ((rc = gen_copy_in(t, t->x, x, kind, B * npix)) || (rc = gen_copy_in(t, t->y, y, kind, B * npix))) return rc;
+
+    // ---- forward, BatchNormalization in training mode
+    for (int l = 0; l < last; ++l) {
+        const int C = t->ch[l], pool = l < t->n_enc;
+        const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+        LCHK(launch_conv_generic(in, P + t->off_k[l], P + t->off_b[l], t->r[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C,
+                                 l > t->n_enc, GEN_EPI_RELU, s));
+        int G1 = 0;
+        LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * t->gh[l] * t->gw[l], C, t->part_stats.as<float>(), &G1, s));
+        LCHK(launch_bn_stats_final(t->part_stats.as<float>(), G1, C, t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l],
+                                   MOV + t->off_mv[l], t->stats[l].as<float>(), s));
+        LCHK(launch_bn_apply(t->r[l].as<float>(), C, P + t->off_g[l], P + t->off_be[l], t->stats[l].as<float>(), t->a[l].as<float>(), B,
+                             t->gh[l], t->gw[l], pool, s));
+    }
+    LCHK(launch_conv_generic(t->a[last - 1].as<float>(), P + t->off_k[last], P + t->off_b[last], t->out.as<float>(), B, t->gh[last],
+                             t->gw[last], t->cin(last), 1, last > t->n_enc, GEN_EPI_SIGMOID, s));
+    LCHK(launch_recon_err(t->out.as<float>(), t->y.as<float>(), B, (int)npix, t->errpart.as<float>(), s));
+    LCHK(launch_loss_scalar(t->errpart.as<float>(), B * 4, B * (long)npix, t->scal.as<float>(), s));
+
+    // ---- backward
+    LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * npix, t->dz[last].as<float>(), t->dzsum_part[last].as<float>(),
+                        &t->np_b[last], s));
+    for (int l = last; l >= 0; --l) {
+        const int C = t->ch[l], pool = l < t->n_enc, ups = l > t->n_enc;
+        if (l < last) {
+            int G2 = 0;
+            LCHK(launch_bn_bwd_reduce(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l], P + t->off_be[l], B,
+                                      t->gh[l], t->gw[l], C, pool, t->part_bwd.as<float>(), &G2, s));
+            LCHK(launch_bn_bwd_final(t->part_bwd.as<float>(), G2, C, (double)B * t->gh[l] * t->gw[l], t->bwd_sums.as<float>(), G + t->off_g[l],
+                                     G + t->off_be[l], s));
+            LCHK(launch_bn_bwd_dz(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l], P + t->off_be[l],
+                                  t->bwd_sums.as<float>(), B, t->gh[l], t->gw[l], C, pool, t->dz[l].as<float>(), t->dzsum_part[l].as<float>(),
+                                  &t->np_b[l], s));
+        }
+        const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+        LCHK(launch_wgrad_generic(in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C, ups, TRAIN_MAX_PARTS,
+                                  &t->np_w[l], s));
+        if (l > 0) {   // dL/d(input of conv l): conv of dz with the flipped kernel, channel roles swapped
+            float* dst = ups ? t->dup.as<float>() : t->da[l - 1].as<float>();
+            LCHK(launch_conv_generic(t->dz[l].as<float>(), t->wft[l].as<float>(), nullptr, dst, B, t->gh[l], t->gw[l], C, t->cin(l), 0,
+                                     GEN_EPI_PLAIN, s));
+            if (ups) LCHK(launch_sumpool2x2(t->dup.as<float>(), t->da[l - 1].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), s));
+        }
+    }
+    // ---- all partial sums -> flat gradient, in workgroup order
+    std::vector<ReduceDesc> d(2 * t->n_conv);
+    long total = 0;
+    for (int l = 0; l < t->n_conv; ++l) {
+        const long klen = 9L * t->cin(l) * t->ch[l];
+        d[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
+        d[2 * l + 1] = ReduceDesc{t->off_b[l], (long)t->ch[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)t->ch[l]};
+        total += klen + t->ch[l];
+    }
+    HIPCHK(hipMemcpyAsync(t->descs.p, d.data(), d.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // `d` is a local: the copy must finish before it dies
+    LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 2 * t->n_conv, total, G, s));
+    float h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, t->scal.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (loss) *loss = h[0];
+    if (mae) *mae = h[1];
+    return CS_OK;
+}
+
+int gen_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae)
+{
+    const int64_t ch = n < 1024 ? n : 1024;
+    int rc = gen_train_ensure_batch(t, ch);
+    if (rc) return rc;
+    hipStream_t s = t->stream;
+    float* P = t->P.as<float>();
+    float* MOV = t->MOV.as<float>();
+    const int last = t->n_conv - 1;
+    const size_t npix = (size_t)t->H * t->W;
+    for (int l = 0; l < last; ++l)
+        LCHK(launch_pack_ep(P + t->off_b[l], P + t->off_g[l], P + t->off_be[l], MOV + t->off_mm[l], MOV + t->off_mv[l], t->cfg.bn_eps, t->ch[l],
+                            t->ep_inf[l].as<float>(), s));
+    double s2 = 0.0, s1 = 0.0;
+    std::vector<float> part;
+    for (int64_t off = 0; off < n; off += ch) {
+        const int64_t nc = (n - off) < ch ? (n - off) : ch;
+        if ((rc = gen_copy_in(t, t->x, x + (size_t)off * npix, kind, (size_t)nc * npix)) ||
+            (rc = gen_copy_in(t, t->y, y + (size_t)off * npix, kind, (size_t)nc * npix)))
+            return rc;
+        for (int l = 0; l < last; ++l) {
+            const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+            LCHK(launch_conv_generic(in, P + t->off_k[l], t->ep_inf[l].as<float>(), t->a[l].as<float>(), nc, t->gh[l], t->gw[l], t->cin(l), t->ch[l],
+                                     l > t->n_enc, l < t->n_enc ? GEN_EPI_BN_POOL : GEN_EPI_BN, s));
+        }
+        LCHK(launch_conv_generic(t->a[last - 1].as<float>(), P + t->off_k[last], P + t->off_b[last], t->out.as<float>(), nc, t->gh[last],
+                                 t->gw[last], t->cin(last), 1, last > t->n_enc, GEN_EPI_SIGMOID, s));
+        LCHK(launch_recon_err(t->out.as<float>(), t->y.as<float>(), nc, (int)npix, t->errpart.as<float>(), s));
+        part.resize((size_t)nc * 8);
+        HIPCHK(hipMemcpyAsync(part.data(), t->errpart.p, part.size() * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < part.size(); i += 2) { s2 += part[i]; s1 += part[i + 1]; }
+    }
+    if (loss) *loss = (float)(s2 / ((double)n * npix));
+    if (mae) *mae = (float)(s1 / ((double)n * npix));
+    return CS_OK;
+}

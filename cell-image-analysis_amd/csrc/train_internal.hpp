@@ -1,0 +1,47 @@
+// train_internal.hpp -- the trainer handle shared by train_api.hip (reference graph, tuned kernels) and
+// train_generic.hip (any instance of the layer grammar, run-time-shaped kernels).
+#pragma once
+#include "api_internal.hpp"
+
+constexpr int TR_MAXL = CS_MAX_CONV;
+
+struct cs_trainer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cs_train_cfg cfg;
+    int64_t maxb = 0;
+    // architecture: ref = the reference graph (64x64, 32-64-32 | 32-64-32-1) on the tuned kernels
+    bool ref = true;
+    int H = 64, W = 64, n_conv = 7, n_enc = 3;
+    int ch[TR_MAXL] = {0}, gh[TR_MAXL] = {0}, gw[TR_MAXL] = {0};       // filters, conv grid of layer l
+    size_t rfl[TR_MAXL] = {0}, afl[TR_MAXL] = {0};                     // per-cell floats: conv-grid tensor, stored (BN/pool) output
+    int cin(int l) const { return l == 0 ? 1 : ch[l - 1]; }
+    // flat parameter layout, Keras order: conv l kernel (HWIO), bias, [gamma, beta]
+    long off_k[TR_MAXL], off_b[TR_MAXL], off_g[TR_MAXL], off_be[TR_MAXL], nparam = 0;
+    long off_mm[TR_MAXL], off_mv[TR_MAXL], nmov = 0;
+    cs::DevBuf P, Gown, M, V, MOV;
+    float* G = nullptr;                 // gradient buffer in use (own or caller's)
+    long step = 0;
+    // packed operands, rebuilt after every update (reference graph: MFMA fragments; generic: flipped/transposed HWIO kernels)
+    cs::DevBuf wf[TR_MAXL], wft[TR_MAXL], w7eff, ep_inf[TR_MAXL];
+    // batch tensors
+    cs::DevBuf x, y, r[TR_MAXL], a[TR_MAXL], out, errpart, dz[TR_MAXL], da[TR_MAXL], stats[TR_MAXL], dup;
+    cs::DevBuf aug_tf, aug_in, aug_out;
+    cs::DevBuf part_stats, part_bwd, bwd_sums, dzsum_part[TR_MAXL], wpart[TR_MAXL], descs, scal, zeros;
+    int np_w[TR_MAXL], np_b[TR_MAXL];
+    bool descs_valid = false;
+    ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+#define LCHK(call)                                                                             \
+    do {                                                                                       \
+        hipError_t le__ = (call);                                                              \
+        if (le__ != hipSuccess) return cs::fail(CS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(le__)); \
+    } while (0)
+
+// train_generic.hip
+int gen_train_setup(cs_trainer* t);                      // buffers that depend on the architecture only
+int gen_train_repack(cs_trainer* t);                     // flipped / transposed kernels for the backward-data convs
+int gen_train_ensure_batch(cs_trainer* t, int64_t b);
+int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae);
+int gen_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae);

@@ -159,8 +159,8 @@ int cs_model_load(const char *model_dir, int device_id, cs_model **out);
  * generic in its input size (CAE_improved_modeltrain.py:184), e.g. BASELINE.json configs[4]: 128x128,
  * filters 32-64-128 | 128-64-32-1 -- runs on run-time-shaped MFMA kernels (csrc/conv_generic.hip):
  * n_conv = 2 n_enc + 1, last conv 1 filter, every conv grid's width a multiple of 16 and <= 128,
- * channel counts multiples of 4.  Anything else: CS_ERR_UNSUPPORTED.  Training handles (cs_train_*)
- * exist for the reference graph only. */
+ * channel counts multiples of 4.  Anything else: CS_ERR_UNSUPPORTED.  Training handles (cs_train_*) take
+ * the same architectures (cs_train_create). */
 int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights *encoder,
                          const cs_detector_params *detector, int device_id, cs_model **out);
 void cs_model_free(cs_model *m);
@@ -169,7 +169,8 @@ void cs_model_free(cs_model *m);
 int cs_model_wait_stream(cs_model *m, void *hip_stream);
 int cs_model_get_info(const cs_model *m, cs_model_info *info);
 /* Cells per internal pass (workspace ~0.4 MB per cell for the reference graph).  Default: automatic -- 16,384 for
- * host input (pipelined staging), up to 65,536 for device-resident input (a ~28 GB workspace); this call fixes it. */
+ * host input (pipelined staging), up to 65,536 for device-resident input (a ~19 GB workspace for the reference graph);
+ * this call fixes it, 0 returns to automatic.  The workspace is sized for min(n, chunk) cells of the largest call so far. */
 int cs_model_set_chunk(cs_model *m, int64_t chunk_cells);
 
 /* ---- the hot path -------------------------------------------------------------- */
@@ -302,7 +303,12 @@ typedef struct cs_train_cfg {
  * Flat layouts -- trainable: per conv l in order {kernel HWIO, bias, [gamma, beta]};
  * moving: per BN l in order {moving_mean, moving_variance}. */
 int cs_train_param_count(int64_t *n_trainable, int64_t *n_moving);
-/* init: starting weights + moving statistics (create_improved_autoencoder, :184-229). */
+/* The same two counts for the architecture of a handle (any instance of the layer grammar). */
+int cs_train_param_count_of(const cs_trainer *t, int64_t *n_trainable, int64_t *n_moving);
+/* init: starting weights + moving statistics (create_improved_autoencoder, :184-229).  The reference graph trains on
+ * kernels tuned for it; any other instance of the layer grammar (see cs_model_from_arrays; additionally every filter
+ * count but the last must divide 256) trains on run-time-shaped kernels (csrc/train_generic.hip) -- BASELINE.json
+ * configs[4]'s 128x128 / 128-channel variant with the same forward_backward -> all-reduce -> apply split. */
 int cs_train_create(const cs_cae_weights *init, const cs_train_cfg *cfg, int device_id, cs_trainer **out);
 void cs_train_free(cs_trainer *t);
 int cs_train_wait_stream(cs_trainer *t, void *hip_stream);

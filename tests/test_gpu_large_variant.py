@@ -117,5 +117,92 @@ def test_unsupported_shapes_are_refused():
         Engine.from_weights(synth.random_cae(seed=1, hw=(64, 64), channels=(32, 64, 32, 32, 1), n_enc=3))
     assert ei.value.status == -6
     from cellscreen.trainer import Trainer
-    with pytest.raises(L.CellScreenError):                       # training exists for the reference graph only
-        Trainer(synth.random_cae(seed=5, hw=LARGE_HW, channels=LARGE_CH, n_enc=3))
+    with pytest.raises(L.CellScreenError) as ei:                 # the BatchNormalization kernels need filter counts dividing 256
+        Trainer(synth.random_cae(seed=5, hw=(64, 128), channels=(48, 48, 48, 48, 48, 48, 1), n_enc=3))
+    assert ei.value.status == -6
+
+
+# ---- training on the run-time-shaped kernels (csrc/train_generic.hip) ------------------------------------------------
+def _activation_pattern(tr, w, n):
+    """The trainer's ReLU masks and max-pool routing from its relu outputs (stage tap 0), for any instance of the grammar
+    (see tests/test_gpu_train.py: fp32 and fp64 disagree on a handful of those discontinuous decisions)."""
+    nl, ne = w.n_conv - 1, w.n_enc
+    masks, args = [], []
+    for l in range(nl):
+        r = tr.tensor(0, l, n)
+        masks.append(r > 0)
+        if l < ne:
+            N, Hh, Ww, C = r.shape
+            win = r.reshape(N, Hh // 2, 2, Ww // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(N, Hh // 2, Ww // 2, C, 4)
+            args.append(np.argmax(win * np.sign(w.bn_gamma[l])[None, None, None, :, None], axis=-1))
+        else:
+            args.append(None)
+    return masks + [None], args + [None]
+
+
+@pytest.mark.parametrize("hw,channels,n", [((64, 128), (8, 16, 32, 32, 16, 8, 1), 5), (LARGE_HW, LARGE_CH, 2)])
+def test_generic_trainer_gradients_against_the_oracle(hw, channels, n):
+    """BASELINE.json configs[4]'s training half: forward (BN batch statistics) + backward of a non-reference instance of the
+    layer grammar -- a small rectangular one and the 128x128 / 128-channel variant -- against oracle/train_oracle.py
+    (numpy float64, pinned to torch autograd) on the trainer's own activation pattern, at the reference graph's bar."""
+    from cellscreen.trainer import Trainer, param_layout, split_flat
+    from oracle import train_oracle as T
+    w = synth.random_cae(seed=13, hw=hw, channels=channels, n_enc=3)
+    y = synth.blob_crops(17, n, hw=hw)
+    x = np.clip(y + np.random.default_rng(3).normal(0, 0.02, y.shape), 0, 1).astype(np.float32)
+    tr = Trainer(w)
+    try:
+        assert tr.n_trainable == w.n_params() - 2 * sum(c for c in channels[:-1])
+        loss, mae = tr.forward_backward(x, y)
+        masks, args = _activation_pattern(tr, w, n)
+        st = T.TrainState(w, dtype=np.float64)
+        ref = T.forward_backward(st, x, y, relu_masks=masks, pool_args=args)
+        free = T.forward_backward(T.TrainState(w, dtype=np.float64), x, y)
+        nl = w.n_conv - 1
+        flips = sum(int(np.sum(m != (r > 0))) for m, r in zip(masks[:nl], free["relu"][:nl]))
+        assert flips <= 1e-5 * sum(m.size for m in masks[:nl])
+        assert abs(loss - ref["loss"]) <= 1e-5 * ref["loss"] and abs(mae - ref["mae"]) <= 1e-5 * ref["mae"]
+        _, mov, g = tr.export_flat(grads=True)
+        got = split_flat(g, param_layout(channels))
+        errs = {}
+        for (name, _shape), gr in zip(param_layout(channels), ref["grads"]):
+            errs[name] = np.linalg.norm(got[name].astype(np.float64) - gr) / max(np.linalg.norm(gr), 1e-30)
+        print("gradient relative L2 errors:", {k: float("%.2e" % v) for k, v in errs.items()})
+        assert max(errs.values()) <= 1e-5, max(errs, key=errs.get)
+        o = 0
+        for l in range(nl):
+            c = channels[l]
+            assert np.allclose(mov[o:o + c], st.mov_mean[l], rtol=1e-5, atol=1e-7); o += c
+            assert np.allclose(mov[o:o + c], st.mov_var[l], rtol=1e-5, atol=1e-7); o += c
+    finally:
+        tr.close()
+
+
+def test_large_variant_trains_and_splits_for_the_gradient_all_reduce():
+    """Trainer(large): the loss falls, evaluate() runs the inference graph, the exported weights load into the engine, and
+    forward_backward -> (the all-reduce of the 1.34 MB flat gradient would go here) -> apply equals step bit for bit."""
+    import torch
+    from cellscreen.trainer import Trainer
+    w = synth.random_cae(seed=5, hw=LARGE_HW, channels=LARGE_CH, n_enc=3, trivial_bn=True)
+    X = torch.from_numpy(synth.blob_crops(31, 64, hw=LARGE_HW)).cuda()
+    a, b = Trainer(w), Trainer(w)
+    assert a.n_trainable == 334_593 - 2 * (32 + 64 + 128 + 128 + 64 + 32)     # SURVEY.md Appendix A.2 counts the moving statistics too
+    g = torch.zeros(a.n_trainable, dtype=torch.float32, device="cuda")
+    a.use_grad_tensor(g)
+    losses = []
+    for s in range(12):
+        xb = X[torch.randint(0, 64, (8,), device="cuda")]
+        la, _ = a.forward_backward(xb, xb)
+        a.apply(1e-3)
+        lb, _ = b.step(xb, xb, 1e-3)
+        assert la == lb
+        losses.append(la)
+    assert losses[-1] < losses[0]
+    pa, ma = a.export_flat()
+    pb, mb = b.export_flat()
+    assert np.array_equal(pa, pb) and np.array_equal(ma, mb) and float(g.abs().max()) > 0
+    ev = a.evaluate(X[:16], X[:16])
+    e = Engine.from_weights(a.weights())
+    _, mse, _ = e.reconstruct(X[:16].cpu().numpy(), want_recon=False)
+    assert abs(float(mse.mean()) - ev[0]) <= 1e-5 * ev[0]
+    e.close(); a.close(); b.close()
