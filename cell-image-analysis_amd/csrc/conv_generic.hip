@@ -12,6 +12,8 @@
 // freedom: any grid with W % 16 == 0 and W <= 128, any cin in {1, 4k}, any cout.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace cs {
 
 namespace {
@@ -215,6 +217,207 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenArgs g)
     }
 }
 
+// ---- version 2 of the MFMA path (cin % 16 == 0, W in {16, 32, 64, 128}) -----------------------------------------------------
+// The first kernel stages two conv rows per item and lets every wave re-fetch its B fragments for 2 x W / 16 tiles: at cin = 128
+// that is one L2 load per four MFMAs and 0.27 of the matrix peak.  Here an item is a strip of SR rows chosen so that a wave owns
+// TPW = 8 or 16 tiles (all of them live accumulators): a B fragment fetched once feeds 8-16 MFMAs, and a 512-thread workgroup
+// (8 waves = nslw 16-filter slices x nmg tile groups) keeps two waves on every SIMD.  Tiles are handed out in vertical pairs
+// (rows 2 rp, 2 rp + 1 of one 16-pixel column block) so that the 2x2 max-pool stays inside a wave.
+struct Gen2Args {
+    const float* in; const float* w; const float* ep; float* out;
+    long n;
+    int H, W, cin, cout, ups, epi, ps;
+    int SR, nmg, nslw;          // strip rows, tile groups, slices per workgroup pass (nmg * nslw = 8)
+};
+
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void conv_generic2_kernel(Gen2Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float strip[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int H = g.H, W = g.W, cin = g.cin, cout = g.cout, ps = g.ps, SR = g.SR;
+    const int Hs = g.ups ? H / 2 : H, Ws = g.ups ? W / 2 : W;
+    const int R = g.ups ? SR / 2 + 2 : SR + 2, WP = Ws + 2;
+    const int TPR = W / 16;                               // tiles per conv row (1, 2, 4, 8)
+    const int nstrip = H / SR;
+    const int cpb = g.nslw * 16;                          // filters per workgroup pass
+    const int ncb = (cout + cpb - 1) / cpb;
+    const int slice = wave % g.nslw, mg = wave / g.nslw;
+    constexpr int PPW = TPW / 2;                          // vertical tile pairs per wave
+
+    const long items = g.n * nstrip * ncb;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int cb = (int)(item % ncb);
+        const long cs_ = item / ncb;
+        const int y0 = (int)(cs_ % nstrip) * SR;
+        const long cell = cs_ / nstrip;
+        const float* src = g.in + (size_t)cell * Hs * Ws * cin;
+        const int ybase = g.ups ? (y0 / 2 - 1) : (y0 - 1);
+
+        __syncthreads();                                  // previous item's readers are done
+        {
+            const int c4n = cin / 4;
+            for (int e = tid; e < R * WP * c4n; e += 512) {
+                const int c4 = e % c4n, pix = e / c4n;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+                *(f32x4*)(strip + pix * ps + 4 * c4) = v;
+            }
+        }
+        __syncthreads();
+
+        const int co = cb * cpb + slice * 16 + li;
+        const bool live = cb * cpb + slice * 16 < cout;   // wave-uniform: this slice exists
+        if (!live) continue;
+        const bool cok = co < cout;
+        // this wave's tiles: pair i -> pair index pi = mg + nmg * i of the strip = (row pair pi / TPR, column block pi % TPR);
+        // tile 2 i is its upper row, 2 i + 1 the lower
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        int tpy[PPW], tpx[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pi = mg + g.nmg * i;
+            tpy[i] = 2 * (pi / TPR);
+            tpx[i] = (pi % TPR) * 16;
+        }
+        const int nq = cin / 16;
+        const float* wl = g.w + co;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int base[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int py = tpy[t >> 1] + (t & 1), px = tpx[t >> 1] + li;
+                int r, c;
+                if (g.ups) {
+                    r = ((y0 + py + dy) >> 1) - ybase;
+                    c = ((px + dx) >> 1) + 1;
+                } else {
+                    r = py + dy + 1;
+                    c = px + dx + 1;
+                }
+                base[t] = (r * WP + c) * ps + 4 * kq;
+            }
+            const float* wt = wl + (size_t)(tap * cin + 4 * kq) * cout;
+            float bn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)j * cout] : 0.0f;
+            for (int q = 0; q < nq; ++q) {
+                float b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = bn[j];
+                if (q + 1 < nq) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)(16 * (q + 1) + j) * cout] : 0.0f;
+                }
+                // one LDS read ahead of the MFMAs that consume it, pinned: without the pins the scheduler hoists all TPW reads
+                // (4 VGPRs each) above the first MFMA and the 16-tile form spills
+                f32x4 a = *(const f32x4*)(strip + base[0] + 16 * q);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    f32x4 an = a;
+                    if (t + 1 < TPW) an = *(const f32x4*)(strip + base[t + 1] + 16 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+                    a = an;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        }
+        // D: lane = channel li of the slice, registers = pixels 4 kq .. 4 kq + 3 of the tile
+        if (cok) {
+            const float bias = g.epi == GEN_EPI_PLAIN ? 0.0f : g.ep[co];
+            if (g.epi == GEN_EPI_BN_POOL) {
+                const float bns = g.ep[cout + co], bnt = g.ep[2 * cout + co];
+                auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+                float* o = g.out + ((size_t)cell * (H / 2) + y0 / 2) * (W / 2) * cout + co;
+#pragma unroll
+                for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float m0 = fmaxf(post(acc[2 * i][2 * h]), post(acc[2 * i][2 * h + 1]));
+                        const float m1 = fmaxf(post(acc[2 * i + 1][2 * h]), post(acc[2 * i + 1][2 * h + 1]));
+                        o[((size_t)(tpy[i] / 2) * (W / 2) + tpx[i] / 2 + 2 * kq + h) * cout] = fmaxf(m0, m1);
+                    }
+            } else {
+                const float bns = g.epi == GEN_EPI_BN ? g.ep[cout + co] : 1.0f, bnt = g.epi == GEN_EPI_BN ? g.ep[2 * cout + co] : 0.0f;
+                float* o = g.out + ((size_t)cell * H + y0) * W * cout + co;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int py = tpy[t >> 1] + (t & 1), px = tpx[t >> 1] + 4 * kq + r;
+                        const float z = acc[t][r] + bias;
+                        float v;
+                        if (g.epi == GEN_EPI_BN) v = fmaf(fmaxf(z, 0.0f), bns, bnt);
+                        else if (g.epi == GEN_EPI_RELU) v = fmaxf(z, 0.0f);
+                        else if (g.epi == GEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-z));
+                        else v = z;
+                        o[((size_t)py * W + px) * cout] = v;
+                    }
+            }
+        }
+    }
+}
+
+// ---- the 1-filter last conv (bias -> sigmoid) on the vector ALU ---------------------------------------------------------------
+// cout = 1 makes the MFMA form waste 15 of 16 output columns (the padded last conv of the 128x128 variant cost as much matrix time
+// as a 64-filter layer).  A thread owns one output pixel: 9 x cin multiply-adds from the staged strip, the kernel read as LDS
+// broadcasts.  Same k order as the MFMA form is not needed for parity: the reconstruction bar is 1e-5 absolute on a sigmoid.
+__global__ __launch_bounds__(256) void conv_last_generic_kernel(GenArgs g, int SR)
+{
+    extern __shared__ __attribute__((aligned(16))) float strip[];
+    const int tid = threadIdx.x;
+    const int H = g.H, W = g.W, cin = g.cin, ps = g.ps;
+    const int Hs = g.ups ? H / 2 : H, Ws = g.ups ? W / 2 : W;
+    const int R = g.ups ? SR / 2 + 2 : SR + 2, WP = Ws + 2;
+    float* wl = strip + R * WP * ps;                      // the kernel [9][cin]
+    for (int e = tid; e < 9 * cin; e += 256) wl[e] = g.w[e];
+    const float bias = g.ep[0];
+    const int nstrip = H / SR, c4n = cin / 4;
+    for (long item = blockIdx.x; item < g.n * nstrip; item += gridDim.x) {
+        const int y0 = (int)(item % nstrip) * SR;
+        const long cell = item / nstrip;
+        const float* src = g.in + (size_t)cell * Hs * Ws * cin;
+        const int ybase = g.ups ? (y0 / 2 - 1) : (y0 - 1);
+        __syncthreads();
+        for (int e = tid; e < R * WP * c4n; e += 256) {
+            const int c4 = e % c4n, pix = e / c4n;
+            const int r = pix / WP, c = pix - r * WP;
+            const int sy = ybase + r, sx = c - 1;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+            *(f32x4*)(strip + pix * ps + 4 * c4) = v;
+        }
+        __syncthreads();
+        for (int p = tid; p < SR * W; p += 256) {
+            const int py = p / W, px = p - py * W;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                int r, c;
+                if (g.ups) { r = ((y0 + py + dy) >> 1) - ybase; c = ((px + dx) >> 1) + 1; }
+                else { r = py + dy + 1; c = px + dx + 1; }
+                const float* a = strip + (r * WP + c) * ps;
+                const float* wt = wl + tap * cin;
+                for (int c4 = 0; c4 < c4n; ++c4) {
+                    const f32x4 av = *(const f32x4*)(a + 4 * c4), wv = *(const f32x4*)(wt + 4 * c4);
+                    s0 = fmaf(av[0], wv[0], s0); s1 = fmaf(av[1], wv[1], s1); s2 = fmaf(av[2], wv[2], s2); s3 = fmaf(av[3], wv[3], s3);
+                }
+            }
+            const float z = ((s0 + s1) + (s2 + s3)) + bias;
+            g.out[((size_t)cell * H + y0 + py) * W + px] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
 // per-cell squared / absolute error partial sums of a reconstruction: errpart[n][4][2], wave w of the
 // workgroup owns partial w (fixed order, deterministic), as conv7_err_kernel lays them out
 __global__ __launch_bounds__(256) void recon_err_kernel(const float* __restrict__ recon, const float* __restrict__ x, int npix,
@@ -258,24 +461,85 @@ int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t wh
     return 1;
 }
 
+// version-2 plan for a layer: SR rows per strip, nmg tile groups x nslw slices = 8 waves, TPW tiles per wave
+static bool gen2_plan(int H, int W, int cin, int cout, int ups, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
+{
+    static const bool off = getenv("CS_GENERIC_V1") != nullptr;
+    if (off || cin % 16 != 0 || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
+    const int slices = (cout + 15) / 16;
+    int ns = 1;
+    while (ns * 2 <= slices && ns < 8) ns *= 2;           // largest power of two <= min(slices, 8)
+    const int mg = 8 / ns, TPR = W / 16, Ws = ups ? W / 2 : W, ps = cin + 4;
+    for (int t = 16; t >= 4; t /= 2) {                    // tiles per wave: as many as registers and LDS allow
+        const int pairs = (t / 2) * mg;                   // vertical tile pairs per strip
+        if (pairs % TPR) continue;
+        const int sr = 2 * pairs / TPR;
+        if (sr < 2 || H % sr) continue;
+        const int R = ups ? sr / 2 + 2 : sr + 2;
+        const size_t bytes = (size_t)R * (Ws + 2) * ps * sizeof(float);
+        if (bytes > 100 * 1024) continue;
+        *SR = sr; *nmg = mg; *nslw = ns; *tpw = t; *lds = bytes;
+        return true;
+    }
+    return false;
+}
+
 hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float* ep, float* out, int64_t n, int H, int W, int cin,
                                int cout, int ups, int epi, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     if (!conv_generic_supported(H, W, cin, cout, nullptr, 0)) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     GenArgs g;
     g.in = in; g.w = w_hwio; g.ep = ep; g.out = out; g.n = n; g.H = H; g.W = W; g.cin = cin; g.cout = cout;
     g.ups = ups; g.epi = epi;
     g.ps = cin == 1 ? 1 : cin + 4;                        // odd number of 16-B slots per pixel
+    hipError_t e = hipSuccess;
+    static const bool v1_only = getenv("CS_GENERIC_V1") != nullptr;
+    if (!v1_only && cout == 1 && epi == GEN_EPI_SIGMOID && cin % 4 == 0 && cin >= 4) {
+        // the 1-filter last conv on the vector ALU: strips of 4 conv rows
+        const int SR = H % 4 == 0 ? 4 : 2, Ws = ups ? W / 2 : W, R = ups ? SR / 2 + 2 : SR + 2;
+        const size_t lds = ((size_t)R * (Ws + 2) * g.ps + 9 * cin) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            const long items = (long)n * (H / SR);
+            const unsigned grid = (unsigned)(items < (long)cus * 8 ? items : (long)cus * 8);
+            e = hipFuncSetAttribute((const void*)conv_last_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(conv_last_generic_kernel, dim3(grid), dim3(256), lds, stream, g, SR);
+            return hipGetLastError();
+        }
+    }
+    int SR = 0, nmg = 0, nslw = 0, tpw = 0;
+    size_t lds2 = 0;
+    if (gen2_plan(H, W, cin, cout, ups, &SR, &nmg, &nslw, &tpw, &lds2)) {
+        Gen2Args a;
+        a.in = in; a.w = w_hwio; a.ep = ep; a.out = out; a.n = n; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.ups = ups; a.epi = epi;
+        a.ps = g.ps; a.SR = SR; a.nmg = nmg; a.nslw = nslw;
+        const long items = (long)n * (H / SR) * ((cout + nslw * 16 - 1) / (nslw * 16));
+        const int per_cu = lds2 <= 76 * 1024 ? 2 : 1;
+        const unsigned grid = (unsigned)(items < (long)cus * per_cu ? items : (long)cus * per_cu);
+#define GEN2_LAUNCH(T)                                                                                                        \
+    do {                                                                                                                      \
+        e = hipFuncSetAttribute((const void*)conv_generic2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e == hipSuccess) hipLaunchKernelGGL(conv_generic2_kernel<T>, dim3(grid), dim3(512), lds2, stream, a);             \
+    } while (0)
+        switch (tpw) {
+            case 4: GEN2_LAUNCH(4); break;
+            case 8: GEN2_LAUNCH(8); break;
+            case 16: GEN2_LAUNCH(16); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef GEN2_LAUNCH
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     const int Ws = ups ? W / 2 : W, R = ups ? 3 : 4;
     const size_t lds = (size_t)R * (Ws + 2) * g.ps * sizeof(float);
     const long items = (long)n * (H / GEN_SR) * ((cout + 63) / 64);
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)(items < (long)cus * 8 ? items : (long)cus * 8);
     const int tps = GEN_SR * W / 16;
-    hipError_t e = hipSuccess;
 #define GEN_LAUNCH(T)                                                                                                     \
     do {                                                                                                                  \
         e = hipFuncSetAttribute((const void*)conv_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

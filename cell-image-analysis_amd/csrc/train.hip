@@ -795,7 +795,7 @@ hipError_t launch_pack_w7eff(const float* w7, float* weff, hipStream_t s)
 hipError_t launch_pack_ep(const float* bias, const float* gamma, const float* beta, const float* mov_mean,
                           const float* mov_var, float eps, int C, float* ep, hipStream_t s)
 {
-    hipLaunchKernelGGL(pack_ep_kernel, dim3(1), dim3(64), 0, s, bias, gamma, beta, mov_mean, mov_var, eps, C, ep);
+    hipLaunchKernelGGL(pack_ep_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, bias, gamma, beta, mov_mean, mov_var, eps, C, ep);
     return hipGetLastError();
 }
 

@@ -21,6 +21,11 @@ for _ in range(steps):
     e.reconstruct(x, want_recon=False)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+e.profile_enable(True); e.profile_reset()
+e.reconstruct(x, want_recon=False)
+prof = {k: round(v["ms"], 3) for k, v in e.profile().items() if v["launches"]}
+e.profile_enable(False)
 macs = 349.18e6
 print(json.dumps({"workload": f"{n} crops 128x128, filters {CH}, CAE forward + reconstruction MSE/MAE", "cells_per_s": n / dt,
-                  "ms_per_step": dt * 1e3, "tflops_algorithmic": 2 * macs * n / dt / 1e12, "frac_fp32_mfma_peak": 2 * macs * n / dt / 157.3e12}))
+                  "ms_per_step": dt * 1e3, "tflops_algorithmic": 2 * macs * n / dt / 1e12, "frac_fp32_mfma_peak": 2 * macs * n / dt / 157.3e12,
+                  "kernel_ms_one_step": prof}))
