@@ -215,6 +215,19 @@ static int copy_in(cs_trainer* t, DevBuf& dst, const float* src, int kind, size_
     return CS_OK;
 }
 
+// loss / mae of the batch -> the caller: a pinned read-back enqueued behind the step's kernels.  Within cs_train_step
+// the wait is left to the single synchronisation at the end of cs_train_apply (one host round trip per step, not three).
+static int finish_forward_backward(cs_trainer* t, float* loss, float* mae)
+{
+    if (!t->hloss) HIPCHK(hipHostMalloc((void**)&t->hloss, 4 * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(t->hloss, t->scal.p, 8, hipMemcpyDeviceToHost, t->stream));
+    if (t->defer_sync) return CS_OK;
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (loss) *loss = t->hloss[0];
+    if (mae) *mae = t->hloss[1];
+    return CS_OK;
+}
+
 int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae)
 {
     if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
@@ -267,23 +280,20 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
         if (l > 0) LCHK(launch_conv_dgrad(l, t->dz[l].as<float>(), t->wft[l].as<float>(), t->da[l - 1].as<float>(), B, s));
     }
     // ---- all partial sums -> flat gradient, in workgroup order -----------------------------
-    ReduceDesc d[14];
     long total = 0;
-    for (int l = 0; l < 7; ++l) {
-        const long klen = 9L * cin_of(l) * kRefChannels[l];
-        d[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
-        d[2 * l + 1] = ReduceDesc{t->off_b[l], (long)kRefChannels[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)kRefChannels[l]};
-        total += klen + kRefChannels[l];
+    for (int l = 0; l < 7; ++l) total += 9L * cin_of(l) * kRefChannels[l] + kRefChannels[l];
+    if (t->descs_batch != B) {          // the partial counts depend on the batch size only
+        for (int l = 0; l < 7; ++l) {
+            const long klen = 9L * cin_of(l) * kRefChannels[l];
+            t->hdescs[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
+            t->hdescs[2 * l + 1] = ReduceDesc{t->off_b[l], (long)kRefChannels[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)kRefChannels[l]};
+        }
+        HIPCHK(hipMemcpyAsync(t->descs.p, t->hdescs, 14 * sizeof(ReduceDesc), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        t->descs_batch = B;
     }
-    HIPCHK(hipMemcpyAsync(t->descs.p, d, sizeof d, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // `d` is a stack array: the copy must finish before it dies
     LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 14, total, G, s));
-    float h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h, t->scal.p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (loss) *loss = h[0];
-    if (mae) *mae = h[1];
-    return CS_OK;
+    return finish_forward_backward(t, loss, mae);
 }
 
 int cs_train_apply(cs_trainer* t, float lr)
@@ -303,9 +313,18 @@ int cs_train_apply(cs_trainer* t, float lr)
 
 int cs_train_step(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float lr, float* loss, float* mae)
 {
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    t->defer_sync = t->ref;             // the generic path keeps its own synchronisation
     int rc = cs_train_forward_backward(t, x, y, batch, kind, loss, mae);
+    t->defer_sync = false;
     if (rc) return rc;
-    return cs_train_apply(t, lr);
+    rc = cs_train_apply(t, lr);         // ends with the step's one synchronisation
+    if (rc) return rc;
+    if (t->ref) {
+        if (loss) *loss = t->hloss[0];
+        if (mae) *mae = t->hloss[1];
+    }
+    return CS_OK;
 }
 
 int cs_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae)

@@ -29,8 +29,16 @@ struct cs_trainer {
     cs::DevBuf aug_tf, aug_in, aug_out;
     cs::DevBuf part_stats, part_bwd, bwd_sums, dzsum_part[TR_MAXL], wpart[TR_MAXL], descs, scal, zeros;
     int np_w[TR_MAXL], np_b[TR_MAXL];
-    bool descs_valid = false;
-    ~cs_trainer() { if (stream) (void)hipStreamDestroy(stream); }
+    // the reduction descriptors depend on the batch size only: uploaded when it changes, from memory that outlives the copy
+    cs::ReduceDesc hdescs[2 * TR_MAXL];
+    int64_t descs_batch = -1;
+    float* hloss = nullptr;             // pinned {loss, mae}: read after the step's single synchronisation
+    bool defer_sync = false;            // cs_train_step: forward_backward leaves its results to the sync at the end of apply
+    ~cs_trainer()
+    {
+        if (hloss) (void)hipHostFree(hloss);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 #define LCHK(call)                                                                             \

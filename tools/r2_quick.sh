@@ -32,3 +32,5 @@ for f in ("bench.json", "bench_nofuse12.json"):
     except Exception as e:
         print(f, "unreadable:", e)
 PY
+timeout -k 10 200 python tools/bench_variant.py > "$OUT/large_variant_bench.json" 2> "$OUT/large_variant_bench.err"; echo "variant rc=$?"; cat "$OUT/large_variant_bench.json"
+timeout -k 10 200 python bench_train.py --steps 500 --warmup 30 > "$OUT/train_bench.json" 2> "$OUT/train_bench.err"; echo "train rc=$?"; cat "$OUT/train_bench.json" | cut -c1-400
