@@ -367,6 +367,104 @@ __global__ __launch_bounds__(512, 2) void conv_generic2_kernel(Gen2Args g)
     }
 }
 
+// ---- the first conv (cin = 1): K = 9 taps padded to 12 = three MFMAs per tile ------------------------------------------------
+// Same tile ownership as version 2; the A operand is one LDS dword per lane and MFMA (lane (pixel li, k = 4 s + kq) reads tap k of its
+// pixel; the padded taps k >= 9 carry zero weights and read tap 0), the three B fragments of the wave's slice stay in registers for
+// the whole launch.  The first kernel spent ~15 address instructions per MFMA on this layer (16 % of the 128x128 variant's time
+// for 1.3 % of its multiply-adds).
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void conv_generic_c1_kernel(Gen2Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float strip[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int H = g.H, W = g.W, cout = g.cout, SR = g.SR;
+    const int R = SR + 2, WP = W + 2;
+    const int TPR = W / 16;
+    const int nstrip = H / SR;
+    const int cpb = g.nslw * 16, ncb = (cout + cpb - 1) / cpb;
+    const int slice = wave % g.nslw, mg = wave / g.nslw;
+    constexpr int PPW = TPW / 2;
+    int toff[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int k = 4 * s + kq, kk = k < 9 ? k : 0;
+        toff[s] = (kk / 3) * WP + (kk % 3) + li;
+    }
+    const long items = g.n * nstrip * ncb;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int cb = (int)(item % ncb);
+        const long cs_ = item / ncb;
+        const int y0 = (int)(cs_ % nstrip) * SR;
+        const long cell = cs_ / nstrip;
+        const float* src = g.in + (size_t)cell * H * W;
+        __syncthreads();
+        for (int e = tid; e < R * WP; e += 512) {
+            const int r = e / WP, c = e - r * WP;
+            const int sy = y0 - 1 + r, sx = c - 1;
+            strip[e] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? src[(size_t)sy * W + sx] : 0.0f;
+        }
+        __syncthreads();
+        const int co = cb * cpb + slice * 16 + li;
+        if (cb * cpb + slice * 16 >= cout) continue;      // wave-uniform: this slice does not exist
+        const bool cok = co < cout;
+        float B[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + kq;
+            B[s] = (cok && k < 9) ? g.w[(size_t)k * cout + co] : 0.0f;
+        }
+        f32x4 acc[TPW];
+        int tpy[PPW], tpx[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pi = mg + g.nmg * i;
+            tpy[i] = 2 * (pi / TPR);
+            tpx[i] = (pi % TPR) * 16;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const float* a = strip + (tpy[t >> 1] + (t & 1)) * WP + tpx[t >> 1];
+            f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[toff[s]], B[s], c, 0, 0, 0);
+            acc[t] = c;
+        }
+        if (cok) {
+            const float bias = g.epi == GEN_EPI_PLAIN ? 0.0f : g.ep[co];
+            if (g.epi == GEN_EPI_BN_POOL) {
+                const float bns = g.ep[cout + co], bnt = g.ep[2 * cout + co];
+                auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+                float* o = g.out + ((size_t)cell * (H / 2) + y0 / 2) * (W / 2) * cout + co;
+#pragma unroll
+                for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float m0 = fmaxf(post(acc[2 * i][2 * h]), post(acc[2 * i][2 * h + 1]));
+                        const float m1 = fmaxf(post(acc[2 * i + 1][2 * h]), post(acc[2 * i + 1][2 * h + 1]));
+                        o[((size_t)(tpy[i] / 2) * (W / 2) + tpx[i] / 2 + 2 * kq + h) * cout] = fmaxf(m0, m1);
+                    }
+            } else {
+                const float bns = g.epi == GEN_EPI_BN ? g.ep[cout + co] : 1.0f, bnt = g.epi == GEN_EPI_BN ? g.ep[2 * cout + co] : 0.0f;
+                float* o = g.out + ((size_t)cell * H + y0) * W * cout + co;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int py = tpy[t >> 1] + (t & 1), px = tpx[t >> 1] + 4 * kq + r;
+                        const float z = acc[t][r] + bias;
+                        float v;
+                        if (g.epi == GEN_EPI_BN) v = fmaf(fmaxf(z, 0.0f), bns, bnt);
+                        else if (g.epi == GEN_EPI_RELU) v = fmaxf(z, 0.0f);
+                        else if (g.epi == GEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-z));
+                        else v = z;
+                        o[((size_t)py * W + px) * cout] = v;
+                    }
+            }
+        }
+    }
+}
+
 // ---- the 1-filter last conv (bias -> sigmoid) on the vector ALU ---------------------------------------------------------------
 // cout = 1 makes the MFMA form waste 15 of 16 output columns (the padded last conv of the 128x128 variant cost as much matrix time
 // as a 64-filter layer).  A thread owns one output pixel: 9 x cin multiply-adds from the staged strip, the kernel read as LDS
@@ -465,11 +563,11 @@ int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t wh
 static bool gen2_plan(int H, int W, int cin, int cout, int ups, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
 {
     static const bool off = getenv("CS_GENERIC_V1") != nullptr;
-    if (off || cin % 16 != 0 || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
+    if (off || !(cin % 16 == 0 || (cin == 1 && !ups)) || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
     const int slices = (cout + 15) / 16;
     int ns = 1;
     while (ns * 2 <= slices && ns < 8) ns *= 2;           // largest power of two <= min(slices, 8)
-    const int mg = 8 / ns, TPR = W / 16, Ws = ups ? W / 2 : W, ps = cin + 4;
+    const int mg = 8 / ns, TPR = W / 16, Ws = ups ? W / 2 : W, ps = cin == 1 ? 1 : cin + 4;
     for (int t = 16; t >= 4; t /= 2) {                    // tiles per wave: as many as registers and LDS allow
         const int pairs = (t / 2) * mg;                   // vertical tile pairs per strip
         if (pairs % TPR) continue;
@@ -525,12 +623,26 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
         e = hipFuncSetAttribute((const void*)conv_generic2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e == hipSuccess) hipLaunchKernelGGL(conv_generic2_kernel<T>, dim3(grid), dim3(512), lds2, stream, a);             \
     } while (0)
+#define GENC1_LAUNCH(T)                                                                                                        \
+    do {                                                                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_generic_c1_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e == hipSuccess) hipLaunchKernelGGL(conv_generic_c1_kernel<T>, dim3(grid), dim3(512), lds2, stream, a);             \
+    } while (0)
+        if (cin == 1) {
+            switch (tpw) {
+                case 4: GENC1_LAUNCH(4); break;
+                case 8: GENC1_LAUNCH(8); break;
+                case 16: GENC1_LAUNCH(16); break;
+                default: return hipErrorInvalidValue;
+            }
+        } else
         switch (tpw) {
             case 4: GEN2_LAUNCH(4); break;
             case 8: GEN2_LAUNCH(8); break;
             case 16: GEN2_LAUNCH(16); break;
             default: return hipErrorInvalidValue;
         }
+#undef GENC1_LAUNCH
 #undef GEN2_LAUNCH
         if (e != hipSuccess) return e;
         return hipGetLastError();

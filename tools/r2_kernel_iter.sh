@@ -13,3 +13,5 @@ import json, sys
 j = json.loads(open(sys.argv[1] + "/bench.json").read().strip().splitlines()[-1])
 print(j["value"], j["ms_per_step"], {k: (round(v["ms"] / j["steps"], 2), v.get("frac_executed")) for k, v in j["kernels"].items()})
 PY
+timeout -k 10 200 python tools/bench_variant.py > "$OUT/variant.json" 2> "$OUT/variant.err"; echo "variant rc=$?"; cat "$OUT/variant.json"
+timeout -k 10 300 python -m pytest tests/test_gpu_large_variant.py -x -q -m gpu > "$OUT/tests_variant.log" 2>&1; echo "variant tests rc=$?"; tail -2 "$OUT/tests_variant.log"
