@@ -80,7 +80,9 @@ hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, flo
                                  float* mov_var, float* stats, hipStream_t s);
 hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const float* beta, const float* stats, float* a,
                            long N, int H, int W, int pool, hipStream_t s);
-hipError_t launch_loss_dz(const float* out, const float* y, long total, float* dz, float* dzsum_part, int* G, hipStream_t s);
+// errpart / nparts / out2 (optional): also reduce the error partial sums of the forward pass to {loss, mae} (saves a launch)
+hipError_t launch_loss_dz(const float* out, const float* y, long total, float* dz, float* dzsum_part, int* G, hipStream_t s,
+                          const float* errpart = nullptr, long nparts = 0, float* out2 = nullptr);
 hipError_t launch_loss_scalar(const float* errpart, long nparts, long nelem, float* out2, hipStream_t s);
 hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
                                 long N, int H, int W, int C, int pool, float* part, int* G, hipStream_t s);

@@ -198,6 +198,7 @@ void cs_train_free(cs_trainer* t)
 {
     if (!t) return;
     (void)hipSetDevice(t->device);
+    if (t->stream2) (void)hipStreamSynchronize(t->stream2);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     delete t;
 }
@@ -258,12 +259,22 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
     }
     LCHK(launch_conv7_err(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6],
                           t->errpart.as<float>(), t->out.as<float>(), B, s));
-    LCHK(launch_loss_scalar(t->errpart.as<float>(), B * 4, B * kH * kW, t->scal.as<float>(), s));
 
     // ---- backward -------------------------------------------------------------------------
+    // The weight gradient of a layer needs only that layer's dz and input; it runs on a second stream beside the
+    // backward-data conv and the BatchNormalization-backward kernels of the layers below, none of which fills the chip at
+    // batch 32.  Both streams join again before the partial sums are reduced.
+    if (!t->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+        for (int l = 0; l < 7; ++l) HIPCHK(hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&t->ev_wg, hipEventDisableTiming));
+    }
+    hipStream_t s2 = t->stream2;
     LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * kH * kW, t->dz[6].as<float>(),
-                        t->dzsum_part[6].as<float>(), &t->np_b[6], s));
-    LCHK(launch_wgrad(6, t->a[5].as<float>(), t->dz[6].as<float>(), t->wpart[6].as<float>(), B, &t->np_w[6], s));
+                        t->dzsum_part[6].as<float>(), &t->np_b[6], s, t->errpart.as<float>(), B * 4, t->scal.as<float>()));
+    HIPCHK(hipEventRecord(t->ev_dz[6], s));
+    HIPCHK(hipStreamWaitEvent(s2, t->ev_dz[6], 0));
+    LCHK(launch_wgrad(6, t->a[5].as<float>(), t->dz[6].as<float>(), t->wpart[6].as<float>(), B, &t->np_w[6], s2));
     LCHK(launch_conv_dgrad(6, t->dz[6].as<float>(), t->wft[6].as<float>(), t->da[5].as<float>(), B, s));
     for (int l = 5; l >= 0; --l) {
         const int C = kRefChannels[l], Hc = kConvGrid[l], pool = l < kNEnc;
@@ -276,9 +287,13 @@ int cs_train_forward_backward(cs_trainer* t, const float* x, const float* y, int
                               P + t->off_be[l], t->bwd_sums.as<float>(), B, Hc, Hc, C, pool, t->dz[l].as<float>(),
                               t->dzsum_part[l].as<float>(), &t->np_b[l], s));
         const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
-        LCHK(launch_wgrad(l, in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, &t->np_w[l], s));
+        HIPCHK(hipEventRecord(t->ev_dz[l], s));
+        HIPCHK(hipStreamWaitEvent(s2, t->ev_dz[l], 0));
+        LCHK(launch_wgrad(l, in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, &t->np_w[l], s2));
         if (l > 0) LCHK(launch_conv_dgrad(l, t->dz[l].as<float>(), t->wft[l].as<float>(), t->da[l - 1].as<float>(), B, s));
     }
+    HIPCHK(hipEventRecord(t->ev_wg, s2));
+    HIPCHK(hipStreamWaitEvent(s, t->ev_wg, 0));
     // ---- all partial sums -> flat gradient, in workgroup order -----------------------------
     long total = 0;
     for (int l = 0; l < 7; ++l) total += 9L * cin_of(l) * kRefChannels[l] + kRefChannels[l];

@@ -235,11 +235,9 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
     LCHK(launch_conv_generic(t->a[last - 1].as<float>(), P + t->off_k[last], P + t->off_b[last], t->out.as<float>(), B, t->gh[last],
                              t->gw[last], t->cin(last), 1, last > t->n_enc, GEN_EPI_SIGMOID, s));
     LCHK(launch_recon_err(t->out.as<float>(), t->y.as<float>(), B, (int)npix, t->errpart.as<float>(), s));
-    LCHK(launch_loss_scalar(t->errpart.as<float>(), B * 4, B * (long)npix, t->scal.as<float>(), s));
-
     // ---- backward
     LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * npix, t->dz[last].as<float>(), t->dzsum_part[last].as<float>(),
-                        &t->np_b[last], s));
+                        &t->np_b[last], s, t->errpart.as<float>(), B * 4, t->scal.as<float>()));
     for (int l = last; l >= 0; --l) {
         const int C = t->ch[l], pool = l < t->n_enc, ups = l > t->n_enc;
         if (l < last) {

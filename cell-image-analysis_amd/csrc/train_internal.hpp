@@ -8,6 +8,8 @@ constexpr int TR_MAXL = CS_MAX_CONV;
 struct cs_trainer {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // weight gradients run here, beside the BatchNormalization-backward chain of the next layer
+    hipEvent_t ev_dz[TR_MAXL] = {nullptr}, ev_wg = nullptr;
     cs_train_cfg cfg;
     int64_t maxb = 0;
     // architecture: ref = the reference graph (64x64, 32-64-32 | 32-64-32-1) on the tuned kernels
@@ -37,6 +39,9 @@ struct cs_trainer {
     ~cs_trainer()
     {
         if (hloss) (void)hipHostFree(hloss);
+        for (auto& e : ev_dz) if (e) (void)hipEventDestroy(e);
+        if (ev_wg) (void)hipEventDestroy(ev_wg);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
