@@ -41,7 +41,7 @@ struct ConvSet {           // one weight set on device, packed for the kernels
 };
 
 // weights of a non-reference architecture, as conv_generic.hip takes them (HWIO kernels + [3][cout] epilogue)
-struct GenSet { DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV]; };
+struct GenSet { DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV], wf[CS_MAX_CONV]; bool folded[CS_MAX_CONV] = {false}; };
 
 // The autoencoder's shape.  ref = the reference graph (64x64, 32-64-32 | 32-64-32-1): tuned kernels;
 // otherwise the same layer grammar with other sizes: conv_generic.hip.
@@ -258,6 +258,14 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
         const int cin = a.cin(l), cout = a.ch[l];
         int rc = upload(set.w[l], w->kernel[l], sizeof(float) * 9 * cin * cout);
         if (rc) return rc;
+        // upsample-fed convs with a folded form: the MFMA phase convs, and the 1-filter last conv on the vector ALU
+        set.folded[l] = l > a.n_enc && ((l < a.n_conv - 1 && conv_generic_folds(a.gh[l], a.gw[l], cin, cout)) ||
+                                        (l == a.n_conv - 1 && cout == 1 && cin % 4 == 0));
+        if (set.folded[l]) {   // upsample-fed conv: effective 2x2 kernels per output phase
+            std::vector<float> wf(pack_generic_folded(cin, cout, nullptr, nullptr));
+            pack_generic_folded(cin, cout, w->kernel[l], wf.data());
+            if ((rc = upload(set.wf[l], wf.data(), wf.size() * sizeof(float)))) return rc;
+        }
         std::vector<float> ep(3 * cout, 0.0f);
         const bool has_bn = w->bn_gamma[l] != nullptr;
         for (int c = 0; c < cout; ++c) {
@@ -414,7 +422,7 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
         const int kid = l < 6 ? K_CONV1 + l : K_CONV7_ERR;       // profile bucket: by position
         LAUNCH(kid, nc,
                launch_conv_generic(in, set.w[l].as<float>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],
-                                   l > a.n_enc, epi, m->stream));
+                                   l > a.n_enc, epi, m->stream, set.folded[l] ? set.wf[l].as<float>() : nullptr));
         if (is_last)
             LAUNCH(K_CONV7_ERR, nc, launch_recon_err(out, x, nc, (int)a.npix, m->errpart.as<float>(), m->stream));
     }

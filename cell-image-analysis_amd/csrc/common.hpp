@@ -101,8 +101,12 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, flo
 // forward with BatchNormalization in batch mode, and the backward-data convs (train_generic.hip)
 enum { GEN_EPI_BN = 0, GEN_EPI_BN_POOL = 1, GEN_EPI_SIGMOID = 2, GEN_EPI_RELU = 3, GEN_EPI_PLAIN = 4 };
 int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t why_len);
+// w_folded (optional, upsample-fed convs only): pack_generic_folded's effective 2x2 kernels; when the layer's shape has a
+// folded plan (conv_generic_folds) the conv runs as four phase convs on the stored grid, 4/9 of the multiply-adds
 hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float* ep, float* out, int64_t n, int H, int W, int cin,
-                               int cout, int ups, int epi, hipStream_t stream);
+                               int cout, int ups, int epi, hipStream_t stream, const float* w_folded = nullptr);
+size_t pack_generic_folded(int cin, int cout, const float* hwio, float* dst);
+int conv_generic_folds(int H, int W, int cin, int cout);
 // run-time-shaped training kernels (train_generic.hip)
 hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s);
 hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int W, int C, hipStream_t s);

@@ -367,6 +367,172 @@ __global__ __launch_bounds__(512, 2) void conv_generic2_kernel(Gen2Args g)
     }
 }
 
+// ---- the 1-filter last conv behind an UpSampling2D, folded: a thread owns one STORED pixel = a 2x2 block of outputs ---------
+// The four outputs read the same 3x3 stored neighbourhood; with the effective 2x2 kernels of the four phases (pack_generic_folded
+// with cout = 1: [phase][tap][cin]) a block costs 9 x cin / 4 activation reads + 16 x cin multiply-adds instead of 4 x 9 x cin.
+__global__ __launch_bounds__(256) void conv_last_folded_kernel(GenArgs g, int SRS /* stored rows per strip */)
+{
+    extern __shared__ __attribute__((aligned(16))) float strip[];
+    const int tid = threadIdx.x;
+    const int H = g.H, W = g.W, cin = g.cin, ps = g.ps;
+    const int Hs = H / 2, Ws = W / 2;
+    const int R = SRS + 2, WP = Ws + 2;
+    float* wl = strip + R * WP * ps;                      // W_eff [4 phases][4 taps][cin]
+    for (int e = tid; e < 16 * cin; e += 256) wl[e] = g.w[e];
+    const float bias = g.ep[0];
+    const int nstrip = Hs / SRS, c4n = cin / 4;
+    for (long item = blockIdx.x; item < g.n * nstrip; item += gridDim.x) {
+        const int ys0 = (int)(item % nstrip) * SRS;
+        const long cell = item / nstrip;
+        const float* src = g.in + (size_t)cell * Hs * Ws * cin;
+        __syncthreads();
+        for (int e = tid; e < R * WP * c4n; e += 256) {
+            const int c4 = e % c4n, pix = e / c4n;
+            const int r = pix / WP, c = pix - r * WP;
+            const int sy = ys0 - 1 + r, sx = c - 1;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+            *(f32x4*)(strip + pix * ps + 4 * c4) = v;
+        }
+        __syncthreads();
+        for (int p = tid; p < SRS * Ws; p += 256) {
+            const int ys = p / Ws, xs = p - ys * Ws;
+            f32x4 s[4];                                   // one 4-lane partial sum per phase
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) s[ph] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int c4 = 0; c4 < c4n; ++c4) {
+                f32x4 nb[3][3];                           // the 3x3 stored neighbourhood, these 4 channels
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) nb[i][j] = *(const f32x4*)(strip + ((ys + i) * WP + xs + j) * ps + 4 * c4);
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int a = ph >> 1, b = ph & 1;
+#pragma unroll
+                    for (int tap = 0; tap < 4; ++tap) {
+                        const f32x4 wv = *(const f32x4*)(wl + (ph * 4 + tap) * cin + 4 * c4);
+                        const f32x4 av = nb[a + (tap >> 1)][b + (tap & 1)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) s[ph][k] = fmaf(av[k], wv[k], s[ph][k]);
+                    }
+                }
+            }
+            float* o = g.out + ((size_t)cell * H + 2 * (ys0 + ys)) * W + 2 * xs;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const float z = ((s[ph][0] + s[ph][1]) + (s[ph][2] + s[ph][3])) + bias;
+                o[(size_t)(ph >> 1) * W + (ph & 1)] = 1.0f / (1.0f + expf(-z));
+            }
+        }
+    }
+}
+
+// ---- upsample-fed convs with the upsample folded into four 2x2-tap phase convs (4/9 of the multiply-adds) ---------------------
+// Nearest x2 upsampling makes the 3x3 taps of output pixel (2y+a, 2x+b) land on only 2x2 stored pixels, so the conv splits into
+// four output phases (a,b), each a 2x2-tap conv over the STORED grid with the taps that share a stored pixel pre-summed on the
+// host (pack_generic_folded; same algebra as conv_mfma.hip's FOLD form, only the order of fp32 roundings changes).  Tiles are
+// phase-pure: 16 stored pixels of a stored row, outputs at stride 2.  A wave owns ALL tiles of the strip for 4 / nmg phases
+// (the tile groups of version 2 become phase groups), so a B fragment still feeds TPW MFMAs.
+template <int TPW>
+__global__ __launch_bounds__(512, 2) void conv_generic2f_kernel(Gen2Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float strip[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int H = g.H, W = g.W, cin = g.cin, cout = g.cout, ps = g.ps, SR = g.SR;
+    const int Hs = H / 2, Ws = W / 2;
+    const int R = SR / 2 + 2, WP = Ws + 2;
+    const int TPRs = Ws / 16;                             // tiles per stored row
+    const int nstrip = H / SR;
+    const int cpb = g.nslw * 16, ncb = (cout + cpb - 1) / cpb;
+    const int slice = wave % g.nslw, mg = wave / g.nslw;
+    const int nph = 4 / g.nmg;                            // phases per wave
+
+    const long items = g.n * nstrip * ncb;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int cb = (int)(item % ncb);
+        const long cs_ = item / ncb;
+        const int y0 = (int)(cs_ % nstrip) * SR;
+        const long cell = cs_ / nstrip;
+        const float* src = g.in + (size_t)cell * Hs * Ws * cin;
+        const int ybase = y0 / 2 - 1;
+
+        __syncthreads();
+        {
+            const int c4n = cin / 4;
+            for (int e = tid; e < R * WP * c4n; e += 512) {
+                const int c4 = e % c4n, pix = e / c4n;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+                *(f32x4*)(strip + pix * ps + 4 * c4) = v;
+            }
+        }
+        __syncthreads();
+
+        const int co = cb * cpb + slice * 16 + li;
+        if (cb * cpb + slice * 16 >= cout) continue;      // wave-uniform
+        const bool cok = co < cout;
+        const int nq = cin / 16;
+        const float bias = cok ? g.ep[co] : 0.0f;
+        const float bns = (cok && g.epi == GEN_EPI_BN) ? g.ep[cout + co] : 1.0f, bnt = (cok && g.epi == GEN_EPI_BN) ? g.ep[2 * cout + co] : 0.0f;
+        for (int pi = 0; pi < nph; ++pi) {
+            const int phase = mg * nph + pi, a = phase >> 1, b = phase & 1;
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int tap = 0; tap < 4; ++tap) {
+                const int ry = tap >> 1, rx = tap & 1;
+                int base[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int ys = t / TPRs, xs = (t % TPRs) * 16 + li;
+                    // LDS row 0 is stored row y0/2 - 1: stored (ys + a - 1 + ry, xs + b - 1 + rx) -> LDS (ys + a + ry, xs + b + rx)
+                    base[t] = ((ys + a + ry) * WP + xs + b + rx) * ps + 4 * kq;
+                }
+                const float* wt = g.w + ((size_t)(phase * 4 + tap) * cin + 4 * kq) * cout + co;
+                float bn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)j * cout] : 0.0f;
+                for (int q = 0; q < nq; ++q) {
+                    float bb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bb[j] = bn[j];
+                    if (q + 1 < nq) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bn[j] = cok ? wt[(size_t)(16 * (q + 1) + j) * cout] : 0.0f;
+                    }
+                    f32x4 av = *(const f32x4*)(strip + base[0] + 16 * q);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        f32x4 an = av;
+                        if (t + 1 < TPW) an = *(const f32x4*)(strip + base[t + 1] + 16 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bb[j], acc[t], 0, 0, 0);
+                        av = an;
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    }
+                }
+            }
+            if (cok) {
+                float* o = g.out + ((size_t)cell * H + y0 + a) * W * cout + (size_t)b * cout + co;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ys = t / TPRs, xs = (t % TPRs) * 16 + 4 * kq + r;
+                        const float z = fmaxf(acc[t][r] + bias, 0.0f);
+                        o[((size_t)(2 * ys) * W + 2 * xs) * cout] = g.epi == GEN_EPI_BN ? fmaf(z, bns, bnt) : z;
+                    }
+            }
+        }
+    }
+}
+
 // ---- the first conv (cin = 1): K = 9 taps padded to 12 = three MFMAs per tile ------------------------------------------------
 // Same tile ownership as version 2; the A operand is one LDS dword per lane and MFMA (lane (pixel li, k = 4 s + kq) reads tap k of its
 // pixel; the padded taps k >= 9 carry zero weights and read tap 0), the three B fragments of the wave's slice stay in registers for
@@ -582,8 +748,60 @@ static bool gen2_plan(int H, int W, int cin, int cout, int ups, int* SR, int* nm
     return false;
 }
 
+// folded-upsample plan: nmg in {1, 2, 4} phase groups, every wave owns all TPW = (SR / 2) (Ws / 16) tiles of the strip
+static bool gen2f_plan(int H, int W, int cin, int cout, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
+{
+    static const bool off = getenv("CS_GENERIC_V1") != nullptr || getenv("CS_GENERIC_NO_FOLD") != nullptr;
+    const int Ws = W / 2;
+    if (off || cin % 16 != 0 || !(Ws == 16 || Ws == 32 || Ws == 64) || cout < 32) return false;
+    const int slices = (cout + 15) / 16;
+    int ns = 2;
+    while (ns * 2 <= slices && ns < 8) ns *= 2;           // 2, 4 or 8 slices per pass -> 4, 2 or 1 phase groups
+    const int mg = 8 / ns, TPRs = Ws / 16, ps = cin + 4;
+    for (int t = 16; t >= 4; t /= 2) {
+        if (t % TPRs) continue;
+        const int srs = t / TPRs;                         // stored rows per strip
+        if (srs < 1 || (H / 2) % srs) continue;
+        const size_t bytes = (size_t)(srs + 2) * (Ws + 2) * ps * sizeof(float);
+        if (bytes > 100 * 1024) continue;
+        *SR = 2 * srs; *nmg = mg; *nslw = ns; *tpw = t; *lds = bytes;
+        return true;
+    }
+    return false;
+}
+
+// Effective 2x2 kernels per output phase: W_eff[a][b][ry][rx] = sum of W[dy][dx] over the taps with ((a+dy)>>1)+1 == a+ry and
+// ((b+dx)>>1)+1 == b+rx, summed in fp32 in (dy,dx) order (as pack_conv_fragments_folded does).  dst: [4 phases][4 taps][cin][cout].
+size_t pack_generic_folded(int cin, int cout, const float* hwio, float* dst)
+{
+    const size_t total = (size_t)16 * cin * cout;
+    if (!dst) return total;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int tap = 0; tap < 4; ++tap) {
+                const int ry = tap >> 1, rx = tap & 1;
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int co = 0; co < cout; ++co) {
+                        float sum = 0.0f;
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx)
+                                if (((a + dy) >> 1) + 1 == a + ry && ((b + dx) >> 1) + 1 == b + rx)
+                                    sum += hwio[((size_t)((dy + 1) * 3 + (dx + 1)) * cin + ci) * cout + co];
+                        dst[((size_t)((a * 2 + b) * 4 + tap) * cin + ci) * cout + co] = sum;
+                    }
+            }
+    return total;
+}
+
+int conv_generic_folds(int H, int W, int cin, int cout)
+{
+    int SR, nmg, nslw, tpw;
+    size_t lds;
+    return gen2f_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds) ? 1 : 0;
+}
+
 hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float* ep, float* out, int64_t n, int H, int W, int cin,
-                               int cout, int ups, int epi, hipStream_t stream)
+                               int cout, int ups, int epi, hipStream_t stream, const float* w_folded)
 {
     if (n <= 0) return hipSuccess;
     if (!conv_generic_supported(H, W, cin, cout, nullptr, 0)) return hipErrorInvalidValue;
@@ -596,6 +814,22 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
     g.ps = cin == 1 ? 1 : cin + 4;                        // odd number of 16-B slots per pixel
     hipError_t e = hipSuccess;
     static const bool v1_only = getenv("CS_GENERIC_V1") != nullptr;
+    static const bool no_fold = getenv("CS_GENERIC_NO_FOLD") != nullptr;
+    if (!v1_only && !no_fold && cout == 1 && epi == GEN_EPI_SIGMOID && ups && w_folded && cin % 4 == 0 && cin >= 4) {
+        const int Hs = H / 2, Ws = W / 2;
+        const int SRS = Hs % 4 == 0 ? 4 : (Hs % 2 == 0 ? 2 : 1);
+        const size_t lds = ((size_t)(SRS + 2) * (Ws + 2) * g.ps + 16 * cin) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            const long items = (long)n * (Hs / SRS);
+            const unsigned grid = (unsigned)(items < (long)cus * 8 ? items : (long)cus * 8);
+            GenArgs gf = g;
+            gf.w = w_folded;
+            e = hipFuncSetAttribute((const void*)conv_last_folded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(conv_last_folded_kernel, dim3(grid), dim3(256), lds, stream, gf, SRS);
+            return hipGetLastError();
+        }
+    }
     if (!v1_only && cout == 1 && epi == GEN_EPI_SIGMOID && cin % 4 == 0 && cin >= 4) {
         // the 1-filter last conv on the vector ALU: strips of 4 conv rows
         const int SR = H % 4 == 0 ? 4 : 2, Ws = ups ? W / 2 : W, R = ups ? SR / 2 + 2 : SR + 2;
@@ -611,6 +845,28 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
     }
     int SR = 0, nmg = 0, nslw = 0, tpw = 0;
     size_t lds2 = 0;
+    if (ups && w_folded && (epi == GEN_EPI_BN || epi == GEN_EPI_RELU) && gen2f_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds2)) {
+        Gen2Args a;
+        a.in = in; a.w = w_folded; a.ep = ep; a.out = out; a.n = n; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.ups = 1; a.epi = epi;
+        a.ps = g.ps; a.SR = SR; a.nmg = nmg; a.nslw = nslw;
+        const long items = (long)n * (H / SR) * ((cout + nslw * 16 - 1) / (nslw * 16));
+        const int per_cu = lds2 <= 76 * 1024 ? 2 : 1;
+        const unsigned grid = (unsigned)(items < (long)cus * per_cu ? items : (long)cus * per_cu);
+#define GEN2F_LAUNCH(T)                                                                                                        \
+    do {                                                                                                                       \
+        e = hipFuncSetAttribute((const void*)conv_generic2f_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e == hipSuccess) hipLaunchKernelGGL(conv_generic2f_kernel<T>, dim3(grid), dim3(512), lds2, stream, a);             \
+    } while (0)
+        switch (tpw) {
+            case 4: GEN2F_LAUNCH(4); break;
+            case 8: GEN2F_LAUNCH(8); break;
+            case 16: GEN2F_LAUNCH(16); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef GEN2F_LAUNCH
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     if (gen2_plan(H, W, cin, cout, ups, &SR, &nmg, &nslw, &tpw, &lds2)) {
         Gen2Args a;
         a.in = in; a.w = w_hwio; a.ep = ep; a.out = out; a.n = n; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.ups = ups; a.epi = epi;
