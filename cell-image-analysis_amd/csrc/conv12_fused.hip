@@ -4,7 +4,7 @@
 //
 // conv2 is Winograd F(4x4, 3x3) (interpolation points 0, +-1, +-2, inf): a 4x4 output tile costs 36
 // multiplies per channel pair where F(2x2,3x3) needed 64 -- 4,608 16x16x4 MFMAs per cell instead of
-// 8,192 (direct: 18,432).  Measured in fp32 emulation before adopting (tools/wino_error_study.py): p2 error
+// 8,192 (direct: 18,432).  Measured in fp32 emulation before adopting (tests/study_wino_error.py): p2 error
 // 1.6e-6 of its range, features 4.3e-7 of theirs (bar 1e-5).  conv1 (2.4 % of the path's MACs) is
 // computed inside the staging of conv2's input rows, so the 131 KB/cell p1 tensor (written by one kernel,
 // read by the next) and one launch disappear.
@@ -180,38 +180,59 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 const f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);           // bias, bn scale, bn shift, sign
                 // pooled outputs of this lane: ring columns 8 xt + 2 kq + {0,1} (+1: halo), channel c1
                 const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
-                auto p1_row = [&](int q) {
-                    float* const row = ring + (q % RING_SLOTS) * RING_ROWF + pwoff;
-                    const float* a = inp + (2 * (q - 1)) * INP_STRIDE;
+                // One row: conv rows 2y, 2y+1 (y = q - 1) of this wave's 16 pixels x 16 channels -> two pooled values per lane.
+                // Rows are processed four at a time in three explicit stages -- all 24 LDS reads, then the 24 MFMAs as eight
+                // interleaved accumulation chains, then the four epilogues -- because left to itself the compiler serialises
+                // each row (read -> wait -> 6 MFMAs -> s_nop -> pool -> write: ~440 cycles per row and wave, 8 rows per group).
+                auto p1_rows4 = [&](int qb, bool last_is_zero_row) {
+                    float a0[4][3], a1[4][3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = (i == 3 && last_is_zero_row) ? qb + 2 : qb + i;        // a valid row; its result is discarded
+                        const float* a = inp + (2 * (q - 1)) * INP_STRIDE;
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            a0[i][s] = a[toff[s]];
+                            a1[i][s] = a[toff[s] + INP_STRIDE];
+                        }
+                    }
+                    f32x4 acc0[4], acc1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc0[i] = acc1[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][s], B1[s], acc0[i], 0, 0, 0);
+                            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], B1[s], acc1[i], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
+                        float v0 = pool_post(acc0[i][0], acc0[i][1], acc1[i][0], acc1[i][1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        float v1 = pool_post(acc0[i][2], acc0[i][3], acc1[i][2], acc1[i][3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        if (i == 3 && last_is_zero_row) v0 = v1 = 0.0f;                     // q = 33: the bottom zero row
+                        row[0] = v0;
+                        row[32] = v1;
+                    }
+                };
+                // rows q = 8 g + 2 .. 8 g + 9 of every group (g = 3: q = 33 is the bottom zero row), plus q = 0 (zero) and q = 1
+                // for g = 0
+                if (g == 0) {
+                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
+                    const float* a = inp;                                                          // q = 1: conv rows 0, 1
                     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
-                        const float a0 = a[toff[s]];
-                        const float a1 = a[toff[s] + INP_STRIDE];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, B1[s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, B1[s], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[toff[s]], B1[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[toff[s] + INP_STRIDE], B1[s], acc1, 0, 0, 0);
                     }
+                    float* const row = ring + RING_ROWF + pwoff;
                     row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
                     row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
-                };
-                // rows q = 8 g + 2 .. 8 g + 9 of every group (g = 3: q = 33 is the bottom zero row), plus q = 0 (zero) and q = 1
-                // for g = 0.  Four rows at a time are unrolled so that their LDS reads are in flight before the first MFMA and
-                // the MFMA chains of different rows interleave (a rolled loop exposed read + MFMA latency per row).
-                if (g == 0) {
-                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
-                    p1_row(1);
                 }
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    const int qb = 8 * g + 2 + 4 * h;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) p1_row(qb + i);
-                    if (qb + 3 == 33) {
-                        if (t2 < 256) *(f32x4*)(ring + (33 % RING_SLOTS) * RING_ROWF + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    } else {
-                        p1_row(qb + 3);
-                    }
-                }
+                p1_rows4(8 * g + 2, false);
+                p1_rows4(8 * g + 6, g == 3);
             }
             C12_STAMP(0)
             __syncthreads();

@@ -8,8 +8,9 @@ fma chain, U = G g G^T evaluated in double and rounded once (what the host packe
 
 Everything is compared with the fp64-evaluated oracle at the bars of tests/helpers.py:
     features  max|err| <= 1e-5 * max|f|          scores  |err| <= 1e-4 * sum|alpha|
-Prints one JSON line per variant.  Not part of the product or the tests; it only imports the oracle
-as a checker (tools/ is measurement tooling).
+Prints one JSON line per variant.  Lives under tests/ because it uses the CPU oracle as its checker (only tests/,
+smoke() and bench.py's cpu_baseline leg may); pytest does not collect it (not a test_*.py file):
+    python tests/study_wino_error.py          [N=48 BLOBS=1 ONLY=F(4x4)]
 """
 import json
 import os
