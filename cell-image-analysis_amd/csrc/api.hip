@@ -1096,7 +1096,8 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV5: v = (wn && m->wino6 && m->wino5) ? 1152 : 2048; break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
             case K_CONV67_FUSED: v = 4608 + 512; break;                     // conv6 phases + conv7's 32 -> 16 contraction
-            case K_CONV12_FUSED: v = 4608 + 1536; break;                    // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct
+            case K_CONV12_FUSED: v = 4608 + 1536 + 48; break;               // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct;
+                                                                            // + the discarded fourth row of a cell's last 4-row batch
             case K_SCALER_PCA: v = (double)m->fpad * m->cpad / 1024.0; break;
             default: v = 0.0;
         }

@@ -94,7 +94,7 @@ hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats,
 hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
                         hipStream_t s);
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, const float* alpha_dev, float b1, float b2, float eps,
                        hipStream_t s);
 // run-time-shaped conv for non-reference architectures (conv_generic.hip)
 // GEN_EPI_RELU (bias -> ReLU, full resolution) and GEN_EPI_PLAIN (the raw sums; ep may be NULL) serve training:

@@ -570,10 +570,11 @@ __global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndes
 
 // Keras Adam: w -= alpha * m / (sqrt(v) + eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float alpha, float b1, float b2, float eps)
+                            float* __restrict__ v, long n, const float* __restrict__ alpha_dev, float b1, float b2, float eps)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const float alpha = *alpha_dev;     // changes every step: read from memory so that the launch itself never does
     const float gi = g[i];
     const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
     const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
@@ -768,7 +769,7 @@ hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_
     return hipGetLastError();
 }
 
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, const float* alpha, float b1, float b2, float eps,
                        hipStream_t s)
 {
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, alpha, b1, b2, eps);

@@ -34,7 +34,7 @@ struct cs_trainer {
     // the reduction descriptors depend on the batch size only: uploaded when it changes, from memory that outlives the copy
     cs::ReduceDesc hdescs[2 * TR_MAXL];
     int64_t descs_batch = -1;
-    float* hloss = nullptr;             // pinned {loss, mae}: read after the step's single synchronisation
+    float* hloss = nullptr;             // pinned {loss, mae, alpha staging, -}: read after the step's single synchronisation
     bool defer_sync = false;            // cs_train_step: forward_backward leaves its results to the sync at the end of apply
     ~cs_trainer()
     {
