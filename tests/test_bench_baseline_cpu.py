@@ -1,0 +1,48 @@
+"""bench.py's `cpu_baseline` leg: the reference's CPU sequence (improved_detection.py:122-142) restated with torch-CPU for the
+two `predict` calls and the real scikit-learn objects for the rest ("counterpart": TensorFlow is absent).  The restatement
+must agree with the fp64-evaluated C oracle -- otherwise the baseline would be timing a different computation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from cellscreen import synth
+from cellscreen.detector_fit import fit_detector
+from oracle import oracle
+
+sys.path.insert(0, H.ROOT)
+
+
+def test_reference_sequence_counterpart_matches_the_oracle():
+    pytest.importorskip("torch")
+    import bench
+    w = synth.random_cae(seed=42)
+    feats = oracle.cae_forward(w, oracle.synth_crops(42, 10_000_000_000, 400), want=("features",))["features"]
+    det, sk = fit_detector(feats, pca_random_state=0)
+    cb, last = bench.cpu_reference_sequence(w, sk, 42, sizes=(32, 96))
+    assert cb["kind"] in ("counterpart", "reference") and cb["unit"] == "cells/s" and cb["value"] > 0
+    assert set(cb["sizes"]) == {"32", "96"} and set(cb["sizes"]["96"]["split_ms"]) == {
+        "autoencoder_predict_and_errors", "encoder_predict", "scaler_pca", "svm_4_calls"}
+    ref = oracle.screen(w, None, det, oracle.synth_crops(42, 0, 96), acc64=True)
+    assert np.max(np.abs(last["mse"] - ref["mse"]) / ref["mse"]) <= 1e-5
+    assert np.max(np.abs(last["mae"] - ref["mae"]) / ref["mae"]) <= 1e-5
+    for name, p in (("cons", det.conservative), ("mod", det.moderate)):
+        tol = H.TOL_DEC_E2E * np.abs(p.dual_coef).sum()
+        assert np.abs(last[f"{name}_score"] - ref[f"{name}_score"]).max() <= tol
+        H.flags_agree(-last[f"{name}_score"], last[f"{name}_pred"], ref[f"{name}_dec"], ref[f"{name}_pred"], tol, name)
+
+
+def test_source_hash_names_the_kernel_sources(tmp_path):
+    """profiles/*_pmc_traffic.json are accepted by bench.py only when they carry this tree's hash."""
+    sys.path.insert(0, os.path.join(H.ROOT, "cell-image-analysis_amd"))
+    import build
+    h = build.source_hash()
+    assert len(h) == 64 and h == build.source_hash()
+    import bench
+    tj, src = bench.committed_pmc_traffic()
+    if tj is not None:
+        assert tj["source_hash"] == h and "source_hash matches" in src
+    else:
+        assert h[:12] in src
