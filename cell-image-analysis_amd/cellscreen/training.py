@@ -225,7 +225,15 @@ class ImprovedAnomalyDetectionTraining:
         enc_only = encoder if encoder.n_conv == encoder.n_enc else encoder.encoder_half()
         full = autoencoder if autoencoder is not None else (encoder if encoder.n_conv > encoder.n_enc else None)
         if full is None:
-            full = self._autoencoder if self._autoencoder is not None else self._padded_autoencoder(enc_only)
+            full = self._autoencoder
+        if full is None:
+            best_path = os.path.join(self.output_dir, "best_autoencoder.keras")
+            if os.path.exists(best_path):
+                full = model_io.cae_from_keras(best_path)      # what improved_detection.py:28 will load beside the detector
+            else:
+                print("Warning: no autoencoder given, trained or found in output_dir: the model_dir written here scores with the "
+                      "detector only (its reconstruction errors come from a zero decoder)")
+                full = self._padded_autoencoder(enc_only)
         e = Engine.from_weights(full, enc_only, device_id=self.device_id)
         crops = np.ascontiguousarray(cell_images, dtype=np.float32)
         if crops.ndim == 4:

@@ -193,6 +193,32 @@ def test_training_class_mirror(tmp_path):
         assert np.array_equal(r[k], r2[k]), k
 
 
+def test_create_anomaly_detector_with_the_reference_signature_alone(tmp_path):
+    """create_anomaly_detector(encoder, cell_images) (CAE_improved_modeltrain.py:394) on a fresh instance: no training run, no
+    autoencoder argument -- the encoder weight set alone is enough to fit and save the detector."""
+    from cellscreen.screening import ProductionMutantScreening
+    from cellscreen.training import ImprovedAnomalyDetectionTraining
+    w = synth.random_cae(seed=42)
+    cells = synth.blob_crops(24, 400)
+    out = str(tmp_path / "det_only")
+    t = ImprovedAnomalyDetectionTraining(out, verbose=0)
+    detectors, scaler, pca = t.create_anomaly_detector(w.encoder_half(), cells)
+    assert set(detectors) == {"Conservative", "Moderate"}
+    s = ProductionMutantScreening(out)
+    r = s.compute_anomaly_scores(list(cells[:40]))
+    feats = s.engine.encode(cells[:40], which=1)
+    dec = detectors["Moderate"].decision_function(pca.transform(scaler.transform(feats.copy())))
+    assert np.abs(-r["moderate_scores"] - dec).max() <= 1e-4 * np.abs(detectors["Moderate"].dual_coef_).sum()
+    # with the autoencoder given, the same call also leaves the reference's file set
+    out2 = str(tmp_path / "full")
+    t2 = ImprovedAnomalyDetectionTraining(out2, verbose=0)
+    t2.create_anomaly_detector(w.encoder_half(), cells, autoencoder=w)
+    for f in spec.REF_MODEL_FILES:
+        assert os.path.exists(os.path.join(out2, f)), f
+    r2 = ProductionMutantScreening(out2).compute_anomaly_scores(list(cells[:40]))
+    assert np.array_equal(r2["moderate_scores"], r["moderate_scores"]) and r2["reconstruction_mse"].max() < 1.0
+
+
 def test_training_with_the_reference_augmentation(tmp_path):
     """The default augment="reference": the generator of CAE_improved_modeltrain.py:246-254 on the GPU, input only (:287);
     augment=None is the opt-out."""
