@@ -47,6 +47,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0              # spec
 FLOP_PER_CELL = 100_270_080        # ALGORITHMIC: 2 x 50,135,040 conv MACs of the reference graph, SURVEY.md section 8d
 FLOP_PER_MFMA = 2048               # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
+FLOP_PER_BF16_MFMA = 16384         # v_mfma_f32_16x16x32_bf16 (kernels that carry the fp32 contraction as six bf16 products)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 16_384 + 18       # algorithmic: read one crop, write 4 fp32/fp64-as-results + 2 int8
 # algorithmic HBM bytes per cell of each kernel family (what it must read + write if nothing is re-read)
 ALG_BYTES = {"conv1_relu_bn_pool": 16384 + 131072, "conv2_relu_bn_pool": 131072 + 65536, "conv3_relu_bn_pool": 65536 + 8192,
@@ -413,6 +415,7 @@ def main():
         kern = {k: v for k, v in prof.items() if v["launches"] > 0}
         total_ms = sum(v["ms"] for v in kern.values())
         ex_tf = lambda v: v["mfma_per_cell"] * FLOP_PER_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12      # noqa: E731
+        bf_tf = lambda v: v["bf16_mfma_per_cell"] * FLOP_PER_BF16_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12      # noqa: E731
         # ---- roofline: dominant kernel by device time, EXECUTED matrix-pipe FLOPs / measured duration
         dom = max((k for k in kern if kern[k]["mfma_per_cell"] > 0), key=lambda k: kern[k]["ms"])
         d = kern[dom]
@@ -453,6 +456,9 @@ def main():
                            tflops_executed=round(ex_tf(v), 2) if v["mfma_per_cell"] > 0 else None,
                            frac_executed=round(ex_tf(v) / FP32_MFMA_PEAK_TFLOPS, 4) if v["mfma_per_cell"] > 0 else None,
                            tflops_algorithmic=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
+                           **({"bf16_mfma_per_cell": v["bf16_mfma_per_cell"],
+                               "tflops_executed_bf16": round(bf_tf(v), 1), "frac_bf16_mfma_peak": round(bf_tf(v) / BF16_MFMA_PEAK_TFLOPS, 4)}
+                              if v.get("bf16_mfma_per_cell", 0) > 0 else {}),
                            hbm_bytes_per_cell=tk[k]["hbm_bytes_per_cell"] if k in tk else None,
                            algorithmic_bytes_per_cell=ALG_BYTES.get(k))
                    for k, v in kern.items()}
@@ -488,7 +494,7 @@ def main():
                            "executed_flop_per_cell": int(exec_flop_per_cell),
                            "tflops_algorithmic": round(value * FLOP_PER_CELL / 1e12 / world, 3),
                            "algorithmic_speedup": round(FLOP_PER_CELL / exec_flop_per_cell, 4),
-                           "note": "executed = sum of the conv kernels' MFMA counts x 2,048 FLOP per cell; algorithmic = the reference graph's 100.27 MFLOP/cell",
+                           "note": "executed = sum of the conv kernels' fp32 MFMA counts x 2,048 FLOP per cell (conv4 runs on bf16 MFMAs and is priced in its kernels[] entry, not here); algorithmic = the reference graph's 100.27 MFLOP/cell",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
                            "hbm_bytes_per_cell_measured": whole_traffic,

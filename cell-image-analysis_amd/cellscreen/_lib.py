@@ -100,6 +100,7 @@ SIGNATURES = {
     "cs_profile_kernel_name": (C.c_char_p, [_I]),
     "cs_profile_get": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_double)]),
     "cs_profile_mfma_per_cell": (_I, [_P, _I, C.POINTER(C.c_double)]),
+    "cs_profile_bf16_mfma_per_cell": (_I, [_P, _I, C.POINTER(C.c_double)]),
     "cs_train_param_count": (_I, [C.POINTER(_L), C.POINTER(_L)]),
     "cs_train_param_count_of": (_I, [_P, C.POINTER(_L), C.POINTER(_L)]),
     "cs_train_create": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSTrainCfg), _I, C.POINTER(_P)]),

@@ -206,6 +206,8 @@ class Engine:
             L.check(self._lib.cs_profile_get(self._h, k, C.byref(ms), C.byref(ln), C.byref(cells), C.byref(fl)))
             mf = C.c_double()
             L.check(self._lib.cs_profile_mfma_per_cell(self._h, k, C.byref(mf)))
+            bf = C.c_double()
+            L.check(self._lib.cs_profile_bf16_mfma_per_cell(self._h, k, C.byref(bf)))
             out[self._lib.cs_profile_kernel_name(k).decode()] = dict(ms=ms.value, launches=ln.value, cells=cells.value, flops=fl.value,
-                                                                      mfma_per_cell=mf.value)
+                                                                      mfma_per_cell=mf.value, bf16_mfma_per_cell=bf.value)
         return out

@@ -33,6 +33,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf c12w1;          // conv1's fragments for the fused kernel (negated for filters with a negative BN scale)
+    DevBuf c4x3, c5x3;     // conv4's / conv5's weights as three bf16 planes (conv45_bf16x3.hip)
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -41,7 +42,10 @@ struct ConvSet {           // one weight set on device, packed for the kernels
 };
 
 // weights of a non-reference architecture, as conv_generic.hip takes them (HWIO kernels + [3][cout] epilogue)
-struct GenSet { DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV], wf[CS_MAX_CONV]; bool folded[CS_MAX_CONV] = {false}; };
+struct GenSet {
+    DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV], wf[CS_MAX_CONV], wx3[CS_MAX_CONV];      // wx3: split-bf16 planes (conv_generic_x3.hip)
+    bool folded[CS_MAX_CONV] = {false}, x3[CS_MAX_CONV] = {false};
+};
 
 // The autoencoder's shape.  ref = the reference graph (64x64, 32-64-32 | 32-64-32-1): tuned kernels;
 // otherwise the same layer grammar with other sizes: conv_generic.hip.
@@ -71,6 +75,8 @@ struct cs_model {
     bool wino6 = getenv("CS_NO_WINO6") == nullptr;         // A/B knob: conv5/conv6 folded-direct instead of F(2x2,2x2) phases
     bool wino5 = getenv("CS_NO_WINO5") == nullptr;         // A/B knob: conv5 only
     bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
+    bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
+    bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
@@ -234,6 +240,20 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             rc = upload(set.winocs[l], tmp.data(), tmp.size() * sizeof(float));
             if (rc) return rc;
         }
+        if (l == 3) {
+            std::vector<uint16_t> planes(pack_conv4_bf16x3(nullptr, nullptr));
+            pack_conv4_bf16x3(w->kernel[l], planes.data());
+            rc = upload(set.c4x3, planes.data(), planes.size() * sizeof(uint16_t));
+            if (rc) return rc;
+        }
+        if (l == 4) {
+            std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
+            pack_generic_folded(cin, cout, w->kernel[l], weff.data());
+            std::vector<uint16_t> planes(pack_conv5_bf16x3(nullptr, nullptr));
+            pack_conv5_bf16x3(weff.data(), planes.data());
+            rc = upload(set.c5x3, planes.data(), planes.size() * sizeof(uint16_t));
+            if (rc) return rc;
+        }
         if (l == 0) {
             tmp.resize(pack_conv12_conv1_fragments(nullptr, nullptr, nullptr));
             pack_conv12_conv1_fragments(w->kernel[l], ep.data() + cout, tmp.data());
@@ -265,6 +285,17 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
             std::vector<float> wf(pack_generic_folded(cin, cout, nullptr, nullptr));
             pack_generic_folded(cin, cout, w->kernel[l], wf.data());
             if ((rc = upload(set.wf[l], wf.data(), wf.size() * sizeof(float)))) return rc;
+            if (l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 1)) {
+                std::vector<uint16_t> pl(pack_generic_bf16x3(16, cin, cout, nullptr, nullptr));
+                pack_generic_bf16x3(16, cin, cout, wf.data(), pl.data());
+                if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
+                set.x3[l] = true;
+            }
+        } else if (l <= a.n_enc && l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 0)) {
+            std::vector<uint16_t> pl(pack_generic_bf16x3(9, cin, cout, nullptr, nullptr));
+            pack_generic_bf16x3(9, cin, cout, w->kernel[l], pl.data());
+            if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
+            set.x3[l] = true;
         }
         std::vector<float> ep(3 * cout, 0.0f);
         const bool has_bn = w->bn_gamma[l] != nullptr;
@@ -420,6 +451,12 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
         float* out = is_last ? (recon ? recon : m->recon.as<float>()) : m->act[l].as<float>();
         const int epi = is_last ? GEN_EPI_SIGMOID : (l < a.n_enc ? GEN_EPI_BN_POOL : GEN_EPI_BN);
         const int kid = l < 6 ? K_CONV1 + l : K_CONV7_ERR;       // profile bucket: by position
+        if (set.x3[l] && m->bf16x3) {
+            LAUNCH(kid, nc,
+                   launch_conv_generic_x3(in, set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],
+                                          l > a.n_enc, epi, m->stream));
+            continue;
+        }
         LAUNCH(kid, nc,
                launch_conv_generic(in, set.w[l].as<float>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],
                                    l > a.n_enc, epi, m->stream, set.folded[l] ? set.wf[l].as<float>() : nullptr));
@@ -448,6 +485,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     }
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        if (l == 4 && m->bf16x3 && m->x3conv5) {
+            LAUNCH(K_CONV5, nc,
+                   launch_conv5_bf16x3(in, set.c5x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_up(l, in, set.winoup[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
@@ -456,6 +498,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_cs(l, in, set.winocs[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
+        if (l == 3 && m->bf16x3) {
+            LAUNCH(K_CONV4, nc,
+                   launch_conv4_bf16x3(in, set.c4x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
         LAUNCH(K_CONV1 + l, nc,
@@ -1092,8 +1139,8 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV1: v = 1536; break;                                  // 256 tiles x 2 slices x 3 K steps
             case K_CONV2: v = wn ? 8192 : 18432; break;                     // F(2x2,3x3): 16 points x 16 groups x 8 x 4
             case K_CONV3: v = (wn && m->wino3) ? 2048 : 4608; break;
-            case K_CONV4: v = 576; break;
-            case K_CONV5: v = (wn && m->wino6 && m->wino5) ? 1152 : 2048; break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
+            case K_CONV4: v = m->bf16x3 ? 0 : 576; break;                   // split-bf16: 432 v_mfma_f32_16x16x32_bf16, a different instruction and peak -- not counted here
+            case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
             case K_CONV67_FUSED: v = 4608 + 512; break;                     // conv6 phases + conv7's 32 -> 16 contraction
             case K_CONV12_FUSED: v = 4608 + 1536 + 48; break;               // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct;
@@ -1103,9 +1150,30 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
         }
     } else if (k <= K_CONV6 || k == K_CONV7_ERR) {
         const int l = k == K_CONV7_ERR ? m->arch.n_conv - 1 : k - K_CONV1;
-        if (l < m->arch.n_conv) {
+        if (l < m->arch.n_conv && !(m->bf16x3 && m->gae.x3[l])) {      // split-bf16 layers: cs_profile_bf16_mfma_per_cell
             const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
             v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * (9.0 * m->arch.cin(l) / 4.0);
+        }
+    }
+    *mfma = v;
+    return CS_OK;
+}
+
+// The same for the kernels that take the fp32 contraction on the bf16 matrix pipe (conv45_bf16x3.hip, conv_generic_x3.hip):
+// v_mfma_f32_16x16x32_bf16 instructions (16,384 FLOP each; six per 16 pixels x 16 filters x 32 channels) per cell.
+int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
+{
+    if (!m || !mfma || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
+    double v = 0.0;
+    if (m->arch.ref) {
+        if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
+        if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products
+    } else if (k <= K_CONV6 && m->bf16x3) {
+        const int l = k - K_CONV1;
+        if (l < m->arch.n_conv && m->gae.x3[l]) {
+            const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
+            const double taps = l > m->arch.n_enc ? 4.0 : 9.0;             // folded upsample: 16 (phase, tap) pairs over a quarter of the grid
+            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * taps * (m->arch.cin(l) / 32.0) * 6.0;
         }
     }
     *mfma = v;

@@ -44,6 +44,12 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
                                int64_t n_cells, hipStream_t stream);
 size_t pack_conv12_fragments(const float* hwio, const float* bn_scale, float* dst);
 size_t pack_conv12_conv1_fragments(const float* hwio, const float* bn_scale, float* dst);
+// conv4 (layer 3) with the fp32 contraction on the bf16 matrix pipe (three-way operand split, six products): conv45_bf16x3.hip
+hipError_t launch_conv4_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+size_t pack_conv4_bf16x3(const float* hwio, uint16_t* dst);     // returns the number of bf16 values
+// conv5 (layer 4) likewise, on the folded-upsample form: weff = pack_generic_folded(32, 64, hwio, .)
+hipError_t launch_conv5_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+size_t pack_conv5_bf16x3(const float* weff, uint16_t* dst);
 // conv5 (layer 4) / conv6 (layer 5), the upsample-fed decoder convs, as four Winograd F(2x2,2x2) phase convs: conv_wino_up.hip
 hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
@@ -106,6 +112,13 @@ int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t wh
 hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float* ep, float* out, int64_t n, int H, int W, int cin,
                                int cout, int ups, int epi, hipStream_t stream, const float* w_folded = nullptr);
 size_t pack_generic_folded(int cin, int cout, const float* hwio, float* dst);
+// the same convs with the fp32 contraction on the bf16 matrix pipe (three-way operand split, six products): conv_generic_x3.hip.
+// Inference only (the weights are split on the host); conv_generic_x3_takes says whether a layer's shape has a plan (ups = the
+// folded-upsample form, fed pack_generic_folded's kernels with ntaps = 16; otherwise the HWIO kernel with ntaps = 9)
+int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups);
+size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_t* dst);     // returns the number of bf16 values
+hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
+                                  int cout, int ups, int epi, hipStream_t stream);
 int conv_generic_folds(int H, int W, int cin, int cout);
 // run-time-shaped training kernels (train_generic.hip)
 hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s);

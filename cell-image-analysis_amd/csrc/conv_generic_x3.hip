@@ -1,0 +1,395 @@
+// conv_generic_x3.hip -- the run-time-shaped conv of conv_generic.hip (version 2 and its folded-upsample form) with the
+// fp32 contraction carried by the bf16 matrix pipe, for the inference path of NON-reference architectures
+// (create_improved_autoencoder(input_shape), CAE_improved_modeltrain.py:184; BASELINE.json configs[4]).
+//
+// Every fp32 operand is split into three bf16 terms (x = x1 + x2 + x3 to 2^-24; conv45_bf16x3.hip has the algebra and
+// the hardware check of the technique) and a product is taken as six v_mfma_f32_16x16x32_bf16 partial products, each
+// exact in the fp32 accumulator: six 16-cycle instructions per 32 channels against eight 32-cycle
+// v_mfma_f32_16x16x4_f32, and the bf16 instruction leaves half of its issue slots to the VALU, LDS and memory
+// instructions around it.
+//   * activations: split ONCE per staged element (5.5 VALU instructions per value) into three bf16 planes kept side by
+//     side in the staged pixel ([x1: cin][x2: cin][x3: cin] + 32 B: 6 cin + 32 B is twice an odd number of 16-byte
+//     slots, which puts the 16 lanes of every ds_read_b128 lane group on 16 distinct slots -- enumerated); a tile's A
+//     fragment of one (tap, 32-channel block) is one ds_read_b128 per plane, all at immediate offsets from one
+//     address register per tile (cin is a template parameter: 32, 64 or 128 -- at 256 no strip of four tile rows fits the LDS);
+//   * weights: split on the host when the model is loaded (pack_generic_bf16x3), read from L2 as one 16-byte load
+//     per lane and plane and (tap, block), reused for every tile the wave owns (TPW = 4 or 8 live accumulators).
+// Tile ownership, strips, epilogues and the folded upsample (four 2x2-tap phase convs on the stored grid, 4/9 of the
+// multiply-adds) are those of conv_generic.hip.  Training keeps the fp32 kernels (its weights change every step).
+#include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace cs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Gen3Args {
+    const float* in;       // stored input [n][Hs][Ws][cin]  (Hs = H/2 for the folded form)
+    const uint16_t* w;     // pack_generic_bf16x3: [step = tap * cin/32 + block][plane][cout_pad][kq][8] bf16
+    const float* ep;       // [3][cout]
+    float* out;
+    long n;
+    int H, W, cin, cout, epi;
+    int SR, nmg, nslw;     // strip rows, tile (phase) groups, slices per workgroup pass (nmg * nslw = 8)
+};
+
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& h1, bf16x4& h2, bf16x4& h3)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 a1 = (__bf16)v[j];
+        const float r1 = v[j] - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;
+        h1[j] = a1;
+        h2[j] = a2;
+        h3[j] = (__bf16)r2;
+    }
+}
+
+// acc += a * b over one 32-channel block, a and b as three bf16 planes: the six products down to 2^-16
+__device__ __forceinline__ f32x4 mac6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int CIN, int TPW, bool FOLD>
+__global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    constexpr int cin = CIN;
+    const int H = g.H, W = g.W, cout = g.cout, SR = g.SR;
+    const int Hs = FOLD ? H / 2 : H, Ws = FOLD ? W / 2 : W;
+    const int R = FOLD ? SR / 2 + 2 : SR + 2, WP = Ws + 2;
+    constexpr int psb = 6 * CIN + 32;                     // bytes per staged pixel: three planes + pad
+    constexpr int PB = 2 * CIN;                           // byte offset of a plane inside the pixel
+    constexpr int nkb = CIN / 32;
+    const int nstrip = H / SR;
+    const int cpb = g.nslw * 16, ncb = (cout + cpb - 1) / cpb;
+    const int coutp = (cout + 15) & ~15;
+    const int slice = wave % g.nslw, mg = wave / g.nslw;
+    const size_t wstep = (size_t)coutp * 4;               // bf16x8 elements per (step, plane)
+
+    const long items = g.n * nstrip * ncb;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int cb = (int)(item % ncb);
+        const long cs_ = item / ncb;
+        const int y0 = (int)(cs_ % nstrip) * SR;
+        const long cell = cs_ / nstrip;
+        const float* src = g.in + (size_t)cell * Hs * Ws * cin;
+        const int ybase = FOLD ? (y0 / 2 - 1) : (y0 - 1);
+
+        __syncthreads();                                  // previous item's readers are done
+        {
+            constexpr int c4n = CIN / 4;
+            for (int e = tid; e < R * WP * c4n; e += 512) {
+                const int c4 = e % c4n, pix = e / c4n;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+                bf16x4 h1, h2, h3;
+                split4(v, h1, h2, h3);
+                char* d = smem + pix * psb + c4 * 8;
+                *(bf16x4*)d = h1;
+                *(bf16x4*)(d + PB) = h2;
+                *(bf16x4*)(d + 2 * PB) = h3;
+            }
+        }
+        __syncthreads();
+
+        const int cbase = cb * cpb + slice * 16;
+        if (cbase >= cout) continue;                      // wave-uniform: this slice does not exist
+        const int co = cbase + li;
+        const bool cok = co < cout;
+        const bf16x8* wl = (const bf16x8*)g.w + (size_t)co * 4 + kq;      // + (step * 3 + plane) * wstep
+        auto load_b = [&](int step, bf16x8 (&b)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = wl[((size_t)step * 3 + p) * wstep];
+        };
+        auto read_a = [&](int off, bf16x8 (&a)[3]) {
+            a[0] = *(const bf16x8*)(smem + off);
+            a[1] = *(const bf16x8*)(smem + off + PB);
+            a[2] = *(const bf16x8*)(smem + off + 2 * PB);
+        };
+        // one (tap, block) step over the wave's TPW tiles: the next tile's three plane reads are issued ahead of the six
+        // MFMAs of the current one and pinned there (unpinned, the scheduler hoists every tile's reads above the first MFMA)
+        auto step_tiles = [&](const int (&base)[TPW], int kb, const bf16x8 (&b)[3], f32x4 (&acc)[TPW]) {
+            bf16x8 a[3];
+            read_a(base[0] + kb * 64, a);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                bf16x8 an[3] = {a[0], a[1], a[2]};
+                if (t + 1 < TPW) read_a(base[t + 1] + kb * 64, an);
+                acc[t] = mac6(a, b, acc[t]);
+                a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+        };
+
+        if constexpr (!FOLD) {
+            constexpr int PPW = TPW / 2;                  // vertical tile pairs per wave
+            const int TPR = W / 16;
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            int tpy[PPW], tpx[PPW];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int pi = mg + g.nmg * i;
+                tpy[i] = 2 * (pi / TPR);
+                tpx[i] = (pi % TPR) * 16;
+            }
+            bf16x8 bn[3];
+            load_b(0, bn);
+            const int nstep = 9 * nkb;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;     // staged coordinates: +1 halo, -1 tap
+                int base[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    base[t] = ((tpy[t >> 1] + (t & 1) + dy) * WP + tpx[t >> 1] + li + dx) * psb + kq * 16;
+#pragma unroll 1
+                for (int kb = 0; kb < nkb; ++kb) {
+                    bf16x8 b[3] = {bn[0], bn[1], bn[2]};
+                    const int s = tap * nkb + kb;
+                    if (s + 1 < nstep) load_b(s + 1, bn);
+                    step_tiles(base, kb, b, acc);
+                }
+            }
+            // D: lane = channel li of the slice, registers = pixels 4 kq .. 4 kq + 3 of the tile
+            if (cok) {
+                const float bias = g.epi == GEN_EPI_PLAIN ? 0.0f : g.ep[co];
+                if (g.epi == GEN_EPI_BN_POOL) {
+                    const float bns = g.ep[cout + co], bnt = g.ep[2 * cout + co];
+                    auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+                    float* o = g.out + ((size_t)cell * (H / 2) + y0 / 2) * (W / 2) * cout + co;
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float m0 = fmaxf(post(acc[2 * i][2 * h]), post(acc[2 * i][2 * h + 1]));
+                            const float m1 = fmaxf(post(acc[2 * i + 1][2 * h]), post(acc[2 * i + 1][2 * h + 1]));
+                            o[((size_t)(tpy[i] / 2) * (W / 2) + tpx[i] / 2 + 2 * kq + h) * cout] = fmaxf(m0, m1);
+                        }
+                } else {
+                    const float bns = g.epi == GEN_EPI_BN ? g.ep[cout + co] : 1.0f, bnt = g.epi == GEN_EPI_BN ? g.ep[2 * cout + co] : 0.0f;
+                    float* o = g.out + ((size_t)cell * H + y0) * W * cout + co;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int py = tpy[t >> 1] + (t & 1), px = tpx[t >> 1] + 4 * kq + r;
+                            const float z = acc[t][r] + bias;
+                            float v;
+                            if (g.epi == GEN_EPI_BN) v = fmaf(fmaxf(z, 0.0f), bns, bnt);
+                            else if (g.epi == GEN_EPI_RELU) v = fmaxf(z, 0.0f);
+                            else if (g.epi == GEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-z));
+                            else v = z;
+                            o[((size_t)py * W + px) * cout] = v;
+                        }
+                }
+            }
+        } else {
+            // folded upsample: the wave owns ALL TPW stored-pixel tiles of the strip for 4 / nmg output phases
+            const int TPRs = Ws / 16;
+            const int nph = 4 / g.nmg;
+            const float bias = cok ? g.ep[co] : 0.0f;
+            const float bns = (cok && g.epi == GEN_EPI_BN) ? g.ep[cout + co] : 1.0f, bnt = (cok && g.epi == GEN_EPI_BN) ? g.ep[2 * cout + co] : 0.0f;
+#pragma unroll 1
+            for (int pi = 0; pi < nph; ++pi) {
+                const int phase = mg * nph + pi, a = phase >> 1, b = phase & 1;
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                bf16x8 bn[3];
+                load_b(phase * 4 * nkb, bn);
+#pragma unroll 1
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int ry = tap >> 1, rx = tap & 1;
+                    int base[TPW];
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const int ys = t / TPRs, xs = (t % TPRs) * 16 + li;
+                        // staged row 0 is stored row y0/2 - 1: stored (ys + a - 1 + ry, xs + b - 1 + rx) -> staged (ys + a + ry, xs + b + rx)
+                        base[t] = ((ys + a + ry) * WP + xs + b + rx) * psb + kq * 16;
+                    }
+#pragma unroll 1
+                    for (int kb = 0; kb < nkb; ++kb) {
+                        bf16x8 bb[3] = {bn[0], bn[1], bn[2]};
+                        const int s = tap * nkb + kb;
+                        if (s + 1 < 4 * nkb) load_b(phase * 4 * nkb + s + 1, bn);
+                        step_tiles(base, kb, bb, acc);
+                    }
+                }
+                if (cok) {
+                    float* o = g.out + ((size_t)cell * H + y0 + a) * W * cout + (size_t)b * cout + co;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ys = t / TPRs, xs = (t % TPRs) * 16 + 4 * kq + r;
+                            const float z = fmaxf(acc[t][r] + bias, 0.0f);
+                            o[((size_t)(2 * ys) * W + 2 * xs) * cout] = g.epi == GEN_EPI_BN ? fmaf(z, bns, bnt) : z;
+                        }
+                }
+            }
+        }
+    }
+}
+
+uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_val(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+constexpr size_t X3_MAX_LDS = 150 * 1024;
+
+// plain form: SR rows per strip, nmg tile groups x nslw slices = 8 waves, TPW tiles per wave (conv_generic.hip's version-2 plan
+// with the three-plane strip's bytes)
+bool x3_plan(int H, int W, int cin, int cout, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
+{
+    if (!(cin == 32 || cin == 64 || cin == 128) || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
+    const int slices = (cout + 15) / 16;
+    int ns = 1;
+    while (ns * 2 <= slices && ns < 8) ns *= 2;
+    const int mg = 8 / ns, TPR = W / 16, psb = 6 * cin + 32;
+    for (int t = 8; t >= 4; t /= 2) {                     // 16 live accumulators + the three-plane fragments spill at 256 VGPRs
+        const int pairs = (t / 2) * mg;
+        if (pairs % TPR) continue;
+        const int sr = 2 * pairs / TPR;
+        if (sr < 2 || H % sr) continue;
+        const size_t bytes = (size_t)(sr + 2) * (W + 2) * psb;
+        if (bytes > X3_MAX_LDS) continue;
+        *SR = sr; *nmg = mg; *nslw = ns; *tpw = t; *lds = bytes;
+        return true;
+    }
+    return false;
+}
+
+// folded form: nmg in {1, 2, 4} phase groups, every wave owns all TPW = (SR / 2) (Ws / 16) tiles of the strip
+bool x3f_plan(int H, int W, int cin, int cout, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
+{
+    const int Ws = W / 2;
+    if (!(cin == 32 || cin == 64 || cin == 128) || !(Ws == 16 || Ws == 32 || Ws == 64) || cout < 32) return false;
+    const int slices = (cout + 15) / 16;
+    int ns = 2;
+    while (ns * 2 <= slices && ns < 8) ns *= 2;
+    const int mg = 8 / ns, TPRs = Ws / 16, psb = 6 * cin + 32;
+    for (int t = 8; t >= 4; t /= 2) {
+        if (t % TPRs) continue;
+        const int srs = t / TPRs;
+        if (srs < 1 || (H / 2) % srs) continue;
+        const size_t bytes = (size_t)(srs + 2) * (Ws + 2) * psb;
+        if (bytes > X3_MAX_LDS) continue;
+        *SR = 2 * srs; *nmg = mg; *nslw = ns; *tpw = t; *lds = bytes;
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups)
+{
+    static const bool off = getenv("CS_NO_BF16X3") != nullptr || getenv("CS_GENERIC_V1") != nullptr;
+    if (off) return 0;
+    int SR, nmg, nslw, tpw;
+    size_t lds;
+    return (ups ? x3f_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds) : x3_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds)) ? 1 : 0;
+}
+
+// w: [ntaps][cin][cout] fp32 (the HWIO kernel with ntaps = 9, or pack_generic_folded's effective kernels with ntaps = 16).
+// dst: [step = tap * cin/32 + block][plane][cout_pad][kq][8]: element j = plane of w[tap][32 block + 8 kq + j][co], zero for co >= cout
+size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_t* dst)
+{
+    const int coutp = (cout + 15) & ~15, nkb = cin / 32;
+    const size_t total = (size_t)ntaps * nkb * 3 * coutp * 32;
+    if (!dst) return total;
+    for (int t = 0; t < ntaps; ++t)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int co = 0; co < coutp; ++co)
+                for (int k = 0; k < 32; ++k) {
+                    const float v = co < cout ? w[((size_t)t * cin + 32 * kb + k) * cout + co] : 0.0f;
+                    const uint16_t w1 = bf16_rne(v);
+                    const float r1 = v - bf16_val(w1);
+                    const uint16_t w2 = bf16_rne(r1);
+                    const float r2 = r1 - bf16_val(w2);
+                    const uint16_t pl[3] = {w1, w2, bf16_rne(r2)};
+                    for (int p = 0; p < 3; ++p) dst[((((size_t)t * nkb + kb) * 3 + p) * coutp + co) * 32 + k] = pl[p];
+                }
+    return total;
+}
+
+hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
+                                  int cout, int ups, int epi, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    int SR = 0, nmg = 0, nslw = 0, tpw = 0;
+    size_t lds = 0;
+    const bool ok = ups ? x3f_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds) : x3_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds);
+    if (!ok || (ups && !(epi == GEN_EPI_BN || epi == GEN_EPI_RELU))) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    Gen3Args a;
+    a.in = in; a.w = wplanes; a.ep = ep; a.out = out; a.n = n; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.epi = epi;
+    a.SR = SR; a.nmg = nmg; a.nslw = nslw;
+    const long items = (long)n * (H / SR) * ((cout + nslw * 16 - 1) / (nslw * 16));
+    const int per_cu = (tpw <= 8 && lds <= 76 * 1024) ? 2 : 1;
+    const unsigned grid = (unsigned)(items < (long)cus * per_cu ? items : (long)cus * per_cu);
+    hipError_t e = hipSuccess;
+#define X3_LAUNCH(C, T, F)                                                                                                          \
+    do {                                                                                                                            \
+        e = hipFuncSetAttribute((const void*)conv_generic_x3_kernel<C, T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((conv_generic_x3_kernel<C, T, F>), dim3(grid), dim3(512), lds, stream, a);           \
+    } while (0)
+#define X3_TPW(C, F)                                       \
+    switch (tpw) {                                         \
+        case 4: X3_LAUNCH(C, 4, F); break;                 \
+        case 8: X3_LAUNCH(C, 8, F); break;                 \
+        default: return hipErrorInvalidValue;              \
+    }
+#define X3_CIN(F)                                          \
+    switch (cin) {                                         \
+        case 32: X3_TPW(32, F); break;                     \
+        case 64: X3_TPW(64, F); break;                     \
+        case 128: X3_TPW(128, F); break;                   \
+        default: return hipErrorInvalidValue;              \
+    }
+    if (ups) { X3_CIN(true); } else { X3_CIN(false); }
+#undef X3_CIN
+#undef X3_TPW
+#undef X3_LAUNCH
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace cs

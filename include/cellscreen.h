@@ -288,6 +288,11 @@ int cs_profile_get(cs_model *m, int kernel_id, double *total_ms, int64_t *launch
  * the kernels this handle runs: the EXECUTED work a roofline fraction is priced with (Winograd / folded-upsample
  * kernels execute fewer multiply-adds than the layer's algorithmic count).  Equals SQ_INSTS_MFMA per cell. */
 int cs_profile_mfma_per_cell(cs_model *m, int kernel_id, double *mfma);
+/* The same for kernels that carry the fp32 contraction on the bf16 matrix pipe (three-way operand split, six
+ * products: conv4 of the reference graph, the MFMA convs of other architectures): v_mfma_f32_16x16x32_bf16
+ * instructions (16,384 FLOP each) per cell; such a kernel reports 0 from cs_profile_mfma_per_cell.
+ * CS_NO_BF16X3=1 in the environment keeps every conv on the fp32 matrix instructions (A/B timing). */
+int cs_profile_bf16_mfma_per_cell(cs_model *m, int kernel_id, double *mfma);
 
 /* ---- training ---------------------------------------------------------------------- */
 typedef struct cs_trainer cs_trainer;

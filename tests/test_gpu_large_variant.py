@@ -95,6 +95,41 @@ def test_rectangular_variant_with_odd_channel_counts():
         e.close()
 
 
+@pytest.mark.parametrize("channels,expect", [((32, 64, 128, 128, 64, 32, 1), {1, 2, 3, 4, 5}), ((32, 40, 32, 32, 40, 32, 1), {1, 4})])
+def test_split_bf16_convs_against_the_fp32_kernels_and_the_oracle(channels, expect, monkeypatch):
+    """csrc/conv_generic_x3.hip: the MFMA convs of a non-reference architecture take the fp32 contraction on the bf16 matrix
+    pipe where the layer's shape has a plan (cin 32 / 64 / 128; plain and folded-upsample forms; a filter count that is
+    not a multiple of 16).  Every layer against the fp64 oracle at the unchanged tolerance, and against the fp32-MFMA
+    kernels (CS_NO_BF16X3=1): different bits where the split-bf16 kernel ran, the same error class."""
+    hw = (64, 128)
+    w = synth.random_cae(seed=13, hw=hw, channels=channels, n_enc=3)
+    x = np.concatenate([synth.synth_crops(5, 0, 3, hw=hw), synth.blob_crops(6, 3, hw=hw)])
+    ref = oracle.cae_forward(w, x, acc64=True, layers=True)["layers"]
+    names = ["conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool", "conv4_relu_bn", "conv5_up_relu_bn", "conv6_up_relu_bn"]
+    e = Engine.from_weights(w)
+    prof = e.profile()
+    on = {l for l in range(6) if prof[names[l]]["bf16_mfma_per_cell"] > 0}
+    assert on >= expect, (on, expect)
+    assert all(prof[names[l]]["mfma_per_cell"] == 0 for l in on) and all(prof[names[l]]["mfma_per_cell"] > 0 for l in set(range(6)) - on)
+    got = [e.layer_output(x, l) for l in range(7)]
+    e.close()
+    monkeypatch.setenv("CS_NO_BF16X3", "1")
+    e = Engine.from_weights(w)
+    assert all(v["bf16_mfma_per_cell"] == 0 for v in e.profile().values())
+    base = [e.layer_output(x, l) for l in range(7)]
+    e.close()
+    errs = {}
+    for l in range(7):
+        want = ref[l].reshape(got[l].shape)
+        ea = H.assert_close_scaled(got[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, split-bf16 path")
+        eb = H.assert_close_scaled(base[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, fp32 path")
+        errs[l] = (float(f"{ea:.2e}"), float(f"{eb:.2e}"))
+        if l in on:
+            assert not np.array_equal(got[l], base[l]), l
+    assert np.array_equal(got[0], base[0])              # conv1 (cin = 1) is the same kernel either way
+    print("layer: (split-bf16, fp32) max err / max|ref| vs the fp64 oracle:", errs, "split-bf16 layers:", sorted(on))
+
+
 def test_separate_encoder_on_the_generic_path(large, crops):
     enc = synth.perturbed_encoder(large)
     e = Engine.from_weights(large, enc)

@@ -63,6 +63,30 @@ def test_each_layer_against_oracle(engine, weights, crops, layer):
         H.assert_close_scaled(got, ref, 1e-5, f"layer {layer}")
 
 
+def test_conv4_split_bf16_contraction_is_in_the_fp32_error_class(weights, crops, monkeypatch):
+    """conv4 takes its fp32 contraction on the bf16 matrix pipe (three-way operand split, six products:
+    csrc/conv45_bf16x3.hip).  Both kernels -- that one and the fp32-MFMA one behind CS_NO_BF16X3 -- are compared
+    with a float64 conv of the SAME p3 (the device's own, bit-identical for both), so only conv4's arithmetic is
+    in the error: both must sit at fp32 rounding level, far inside the 1e-5 layer tolerance."""
+    e = Engine.from_weights(weights)
+    p3, a4 = e.layer_output(crops, 2), e.layer_output(crops, 3)
+    e.close()
+    monkeypatch.setenv("CS_NO_BF16X3", "1")
+    e = Engine.from_weights(weights)
+    assert np.array_equal(e.layer_output(crops, 2), p3)
+    b4 = e.layer_output(crops, 3)
+    e.close()
+    assert not np.array_equal(a4, b4)                      # the knob really switches kernels
+    k = weights.kernels[3].astype(np.float64)
+    xp = np.pad(p3.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 8, dx:dx + 8, :], k[dy, dx]) for dy in range(3) for dx in range(3))
+    s = weights.bn_gamma[3].astype(np.float64) / np.sqrt(weights.bn_var[3].astype(np.float64) + weights.bn_eps)
+    ref = np.maximum(z + weights.biases[3], 0.0) * s + (weights.bn_beta[3] - weights.bn_mean[3] * s)
+    ea = H.assert_close_scaled(a4, ref, 2e-6, "conv4, split-bf16 contraction")
+    eb = H.assert_close_scaled(b4, ref, 2e-6, "conv4, fp32 matrix instructions")
+    print(f"conv4 max err / max|ref|: split-bf16 {ea:.3e}, fp32 MFMA {eb:.3e}")
+
+
 def test_golden_cae_vectors(golden_cae):
     g = golden_cae
     e = Engine.from_weights(H.cae_from_golden(g))
