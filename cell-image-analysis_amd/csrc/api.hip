@@ -33,7 +33,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf c12w1;          // conv1's fragments for the fused kernel (negated for filters with a negative BN scale)
-    DevBuf c4x3, c5x3;     // conv4's / conv5's weights as three bf16 planes (conv45_bf16x3.hip)
+    DevBuf c4x3, c5x3, c6x3;   // conv4's / conv5's / conv6's weights as three bf16 planes (conv45_bf16x3.hip, conv67_x3_kernel)
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -77,6 +77,7 @@ struct cs_model {
     bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
     bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
     bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
+    bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
@@ -252,6 +253,14 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             std::vector<uint16_t> planes(pack_conv5_bf16x3(nullptr, nullptr));
             pack_conv5_bf16x3(weff.data(), planes.data());
             rc = upload(set.c5x3, planes.data(), planes.size() * sizeof(uint16_t));
+            if (rc) return rc;
+        }
+        if (l == 5) {
+            std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
+            pack_generic_folded(cin, cout, w->kernel[l], weff.data());
+            std::vector<uint16_t> planes(pack_conv6_bf16x3(nullptr, nullptr));
+            pack_conv6_bf16x3(weff.data(), planes.data());
+            rc = upload(set.c6x3, planes.data(), planes.size() * sizeof(uint16_t));
             if (rc) return rc;
         }
         if (l == 0) {
@@ -508,7 +517,12 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         LAUNCH(K_CONV1 + l, nc,
                launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, l == 4 || l == 5));
     }
-    if (fused) {
+    if (fused && m->bf16x3 && m->x3conv6) {
+        LAUNCH(K_CONV67_FUSED, nc,
+               launch_conv67_x3(m->act[4].as<float>(), set.c6x3.as<uint16_t>(), set.ep[5].as<float>(), x, m->w7eff.as<float>(),
+                                m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
+        m->errparts = conv67_fused_nparts();
+    } else if (fused) {
         LAUNCH(K_CONV67_FUSED, nc,
                launch_conv67_fused(m->act[4].as<float>(), set.winoup[5].as<float>(), set.ep[5].as<float>(), x, m->w7eff.as<float>(),
                                    m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
@@ -1142,7 +1156,7 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV4: v = m->bf16x3 ? 0 : 576; break;                   // split-bf16: 432 v_mfma_f32_16x16x32_bf16, a different instruction and peak -- not counted here
             case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
-            case K_CONV67_FUSED: v = 4608 + 512; break;                     // conv6 phases + conv7's 32 -> 16 contraction
+            case K_CONV67_FUSED: v = (m->bf16x3 && m->x3conv6) ? 512 : 4608 + 512; break;   // conv6 phases (unless on bf16 MFMAs) + conv7's 32 -> 16 contraction
             case K_CONV12_FUSED: v = 4608 + 1536 + 48; break;               // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct;
                                                                             // + the discarded fourth row of a cell's last 4-row batch
             case K_SCALER_PCA: v = (double)m->fpad * m->cpad / 1024.0; break;
@@ -1168,6 +1182,7 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
     if (m->arch.ref) {
         if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products
+        if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6) v = 4.0 * 16 * 2 * 4 * 2 * 6;   // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6
     } else if (k <= K_CONV6 && m->bf16x3) {
         const int l = k - K_CONV1;
         if (l < m->arch.n_conv && m->gae.x3[l]) {

@@ -65,6 +65,10 @@ size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);
 hipError_t launch_conv67_fused(const float* a5, const float* ufrag, const float* ep, const float* x, const float* weff_dev,
                                const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
 int conv67_fused_nparts();
+// the same kernel with conv6 (folded direct form) on the bf16 matrix pipe: wplanes = pack_conv6_bf16x3(pack_generic_folded(64, 32, hwio, .))
+hipError_t launch_conv67_x3(const float* a5, const uint16_t* wplanes, const float* ep, const float* x, const float* weff_dev,
+                            const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
+size_t pack_conv6_bf16x3(const float* weff, uint16_t* dst);
 
 // weff_dev: device, [16][32] effective weights (conv7_effective_weights / launch_pack_w7eff);
 // b7_dev: device, the conv's bias; errpart: [n][4][2]; recon (may be null): [n][64][64].

@@ -24,6 +24,7 @@ N_SIMD = 256 * 4
 
 def main():
     out = collections.defaultdict(dict)
+    x3 = set()      # families whose main contraction ran as v_mfma_f32_16x16x32_bf16 (16 cycles each, VALU may issue beside them)
     for d in sys.argv[1:]:
         # the newest pass if the directory was reused
         rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime))))
@@ -34,6 +35,8 @@ def main():
             for k, counters in by.items():
                 if pat not in k:
                     continue
+                if "x3_kernel" in pat:
+                    x3.add(name)
                 for c, v in counters.items():
                     longest = max(x[1] for x in v)
                     full = [x for x in v if x[1] > 0.7 * longest]
@@ -41,6 +44,13 @@ def main():
                     out[name]["launch_ms_under_pmc"] = round(sum(x[1] for x in full) / len(full) / 1e6, 3)
     for name, c in out.items():
         if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c:
+            if name in x3:
+                # bf16 MFMAs: 16 cycles each; the fused conv6 + conv7 kernel also issues 512 fp32 MFMAs (32 cycles) per cell
+                f32 = 512 * 65536 if name == "conv6_conv7_fused_err" else 0
+                c["mfma_kind"] = "v_mfma_f32_16x16x32_bf16" + (" + 512 v_mfma_f32_16x16x4_f32 per cell" if f32 else "")
+                c["simd_cycles_mfma"] = 16 * (c["SQ_INSTS_MFMA"] - f32) + 32 * f32
+                c["mfma_util_at_2p1_ghz"] = round(c["simd_cycles_mfma"] / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3 * 2.1e9), 3)
+                continue
             cyc = 32 * c["SQ_INSTS_MFMA"] + 4 * (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"])
             c["simd_cycles_mfma_plus_valu"] = cyc
             c["implied_clock_ghz_if_fully_busy"] = round(cyc / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3) / 1e9, 3)

@@ -27,6 +27,9 @@ for layer, groups in ((1, 16), (2, 4)):
     tot = sum(v[:5])
     items = N * groups / 512
     key = [k for k in prof if k.startswith(f"conv{layer + 1}_")][0]
+    if rc != 0 or not prof[key]["launches"]:
+        print(f"conv{layer + 1}: its stand-alone Winograd kernel did not run (rc {rc}; conv1 + conv2 run fused unless CS_NO_FUSE12=1)")
+        continue
     ms = prof[key]["ms"] / prof[key]["launches"]
     print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4096); "
           f"launch {ms:.3f} ms -> s_memtime rate {tot / (ms * 1e-3) / 1e9:.3f} GHz")
@@ -44,18 +47,21 @@ for layer, groups in ((5, 4), (4, 1)):
     v = list(out)
     tot = sum(v)
     items = N * groups / 256
+    if rc != 0 or tot == 0:
+        print(f"conv{layer + 1}: its Winograd phase kernel did not run (rc {rc}; conv5 runs on the split-bf16 kernel unless CS_NO_BF16X3=1)")
+        continue
     print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608)")
     for n_, a in zip(names5, v):
         print(f"    {n_:18s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
 
 # the fused conv6 + conv7 + error kernel (slot 3), one workgroup per CU, 4 groups per cell
 f = e.reconstruct(x, want_recon=False)
-names67 = ["load issue", "transform+MFMA", "out transform+a6->LDS+barrier", "T+strip writes+barrier", "gather+sigmoid+err"]
+names67 = ["load issue", "(transform+)MFMA", "(out transform+)a6->LDS+barrier", "T+strip writes+barrier", "gather+sigmoid+err"]
 out = (C.c_double * 5)()
 rc = lib.cs_debug_wino_up_diag(3, out)
 v = list(out)
 tot = sum(v)
 items = N * 4 / 256
-print(f"conv6+7 fused: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608 + 512)")
+print(f"conv6+7 fused: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue per wave pair: Winograd fp32 form 4608 + 512, split-bf16 form 6144 + 512)")
 for n_, a in zip(names67, v):
     print(f"    {n_:30s} {a / items:8.0f} cycles/group  {100 * a / tot:5.1f} %")
