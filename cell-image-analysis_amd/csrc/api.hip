@@ -77,6 +77,7 @@ struct cs_model {
     bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
     bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
     bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
+    bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
@@ -85,7 +86,7 @@ struct cs_model {
     // detector
     bool has_det = false;
     int F = 0, fpad = 0, C = 0, cpad = 0;
-    DevBuf center, scale, comps, mean_proj;
+    DevBuf center, scale, comps, comps_x3, mean_proj;     // comps_x3: components_ as three bf16 planes (scaler_pca_x3_kernel)
     struct Svm { DevBuf svT, svn, coef; int nsv = 0, nsv_pad = 0; double gamma = 0, rho = 0; } svm[2];
     // workspace (per chunk)
     int64_t chunk = 0;     // cells per internal pass; 0 = automatic (eff_chunk), otherwise what cs_model_set_chunk asked for
@@ -690,6 +691,11 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
         for (int c = 0; c < m->C; ++c)
             memcpy(&cp[(size_t)c * m->fpad], det->pca_components + (size_t)c * m->F, sizeof(float) * m->F);
         FAIL_IF(upload(m->comps, cp.data(), cp.size() * sizeof(float)));
+        {
+            std::vector<uint16_t> pl(pack_pca_bf16x3(nullptr, m->cpad, m->fpad, nullptr));
+            pack_pca_bf16x3(cp.data(), m->cpad, m->fpad, pl.data());
+            FAIL_IF(upload(m->comps_x3, pl.data(), pl.size() * sizeof(uint16_t)));
+        }
         FAIL_IF(upload(m->mean_proj, det->pca_mean_proj, sizeof(float) * m->C));
         FAIL_IF(pack_svm(m->svm[0], det->conservative, m->C, "conservative"));
         FAIL_IF(pack_svm(m->svm[1], det->moderate, m->C, "moderate"));
@@ -837,9 +843,14 @@ int cs_model_set_chunk(cs_model* m, int64_t chunk_cells)
 static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, float* mae, double* sc, double* sm,
                     int8_t* pc, int8_t* pm, bool with_err)
 {
-    LAUNCH(K_SCALER_PCA, nc,
-           launch_scaler_pca(feat, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
-                             m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+    if (m->bf16x3 && m->x3pca)
+        LAUNCH(K_SCALER_PCA, nc,
+               launch_scaler_pca_x3(feat, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
+                                    m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+    else
+        LAUNCH(K_SCALER_PCA, nc,
+               launch_scaler_pca(feat, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
+                                 m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
     for (int d = 0; d < 2; ++d)
         LAUNCH(K_SVM, nc,
                launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
@@ -1042,9 +1053,14 @@ int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, fl
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* f;
         if ((rc = stage_in(m, features, in_kind, off, nc, (size_t)m->F, m->featE, &f))) return rc;
-        LAUNCH(K_SCALER_PCA, nc,
-               launch_scaler_pca(f, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
-                                 m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+        if (m->bf16x3 && m->x3pca)
+            LAUNCH(K_SCALER_PCA, nc,
+                   launch_scaler_pca_x3(f, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
+                                        m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+        else
+            LAUNCH(K_SCALER_PCA, nc,
+                   launch_scaler_pca(f, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
+                                     m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
         HIPCHK(hipMemcpyAsync(pca_out + (size_t)off * m->C, m->pca.p, (size_t)nc * m->C * sizeof(float),
                               out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
@@ -1159,7 +1175,7 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV67_FUSED: v = (m->bf16x3 && m->x3conv6) ? 512 : 4608 + 512; break;   // conv6 phases (unless on bf16 MFMAs) + conv7's 32 -> 16 contraction
             case K_CONV12_FUSED: v = 4608 + 1536 + 48; break;               // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct;
                                                                             // + the discarded fourth row of a cell's last 4-row batch
-            case K_SCALER_PCA: v = (double)m->fpad * m->cpad / 1024.0; break;
+            case K_SCALER_PCA: v = (m->bf16x3 && m->x3pca) ? 0.0 : (double)m->fpad * m->cpad / 1024.0; break;
             default: v = 0.0;
         }
     } else if (k <= K_CONV6 || k == K_CONV7_ERR) {
@@ -1179,6 +1195,10 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
 {
     if (!m || !mfma || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
     double v = 0.0;
+    if (k == K_SCALER_PCA && m->bf16x3 && m->x3pca && m->has_det) {
+        *mfma = (double)(m->cpad / 16) * (m->fpad / 32) * 6.0 / 16.0;      // per 16-cell tile: component tiles x 32-feature blocks x 6
+        return CS_OK;
+    }
     if (m->arch.ref) {
         if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products

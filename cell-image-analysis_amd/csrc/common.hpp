@@ -148,6 +148,12 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
                              const float* comps_pad, const float* mean_proj, int F, int fpad, int C,
                              int cpad, float* pca_out, int64_t n_cells, hipStream_t stream);
 
+// the same on the bf16 matrix pipe (six split products per multiply): comps_planes = pack_pca_bf16x3(comps_pad, cpad, fpad, .)
+hipError_t launch_scaler_pca_x3(const float* feat, const float* center, const double* scale, const uint16_t* comps_planes,
+                                const float* mean_proj, int F, int fpad, int C, int cpad, float* pca_out, int64_t n_cells,
+                                hipStream_t stream);
+size_t pack_pca_bf16x3(const float* comps_pad, int cpad, int fpad, uint16_t* dst);     // returns the number of bf16 values
+
 // One-class SVM decision for one detector.  sv: [nsv_pad][D] row-major, svT: [D][nsv_pad]
 // (transposed), coef: [nsv_pad]; all zero padded.  dec[n] = sum - rho.
 hipError_t launch_ocsvm(const float* pca, int D, const double* svT /* [D][nsv_pad] */, const double* svn /* ||sv||^2 */,

@@ -503,7 +503,12 @@ struct F67X {
     static constexpr int PLB = 2 * 64;                         // byte offset of a plane inside the pixel
     static constexpr int ROWB = 18 * PXB;
     static constexpr int STRIP = 6 * ROWB;                     // 44,928 B
-    static constexpr int LDS = STRIP + F67::A6_BYTES + F67::T_BYTES + F67::W_BYTES;
+    // T ring, n-major: [ring row 16][n 16][x 34 -> 36].  The gather's 32 lanes of a ds_read_b32 are 16 columns x 2 column phases;
+    // with the (x, n) order of the fp32 kernel a phase step is 64 B + 16 B and the 32 lanes fall on 4 banks (8-way, a third of
+    // this kernel's LDS cycles); here a phase step is 4 rows + 1 float = 145 floats = 17 banks: 31 distinct banks
+    static constexpr int TW = 36;
+    static constexpr int T_BYTES = F67::TSLOTS * 16 * TW * 4;  // 36,864 B
+    static constexpr int LDS = STRIP + F67::A6_BYTES + T_BYTES + F67::W_BYTES;
     static_assert(LDS <= 160 * 1024 && STRIP % 16 == 0, "LDS budget");
 };
 
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a6s = (float*)(smem + F67X::STRIP);
     float* tb = (float*)(smem + F67X::STRIP + F67::A6_BYTES);
-    float* wl = (float*)(smem + F67X::STRIP + F67::A6_BYTES + F67::T_BYTES);
+    float* wl = (float*)(smem + F67X::STRIP + F67::A6_BYTES + F67X::T_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ph = wave >> 1, wsl = wave & 1;
@@ -682,9 +687,10 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
                     t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
                     t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
                 }
-                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * F67::TWD) + 4 * kq + 1) * 16 + li;
+                // T[ring row][n = li][x + 1]: n-major rows (see F67X)
+                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67X::TW + 4 * kq + 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { tw[r * 16] = t0[r]; tw[(16 + r) * 16] = t1[r]; }
+                for (int r = 0; r < 4; ++r) { tw[r] = t0[r]; tw[16 + r] = t1[r]; }
             }
             if (has_next) {      // every wave is past the first barrier: nobody reads the current strip any more
 #pragma unroll
@@ -700,10 +706,10 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
                 const int y = 8 * grp + (k >> 1), e = k & 1;
                 if (2 * y - 1 + e < 0) continue;
                 const int nb = ((1 - e) * 2 + px) * 4;
-                const float* ra = tb + (((y - 1) & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
-                const float* rb = tb + ((y & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
-                float ta0 = ra[0], ta1 = ra[16 + 1];
-                const float tb0 = rb[2], tb1 = rb[16 + 3];
+                const float* ra = tb + ((((y - 1) & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
+                const float* rb = tb + (((y & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
+                float ta0 = ra[0], ta1 = ra[F67X::TW + 1];
+                const float tb0 = rb[2 * F67X::TW], tb1 = rb[3 * F67X::TW + 1];
                 if (y == 0) { ta0 = 0.0f; ta1 = 0.0f; }                                  // row -1: zero padding
                 const float v = ((ta0 + ta1) + (tb0 + tb1)) + b7;
                 const float rr = f67_sigmoid(v);
@@ -713,8 +719,8 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
             }
             if (grp == C::NGRP - 1 && wave == 0) {                                      // output row 63: a6 row 31 and the padding
                 const int nb = (2 + px) * 4;
-                const float* ra = tb + ((31 & (F67::TSLOTS - 1)) * F67::TWD + xh) * 16 + nb;
-                const float v = (ra[0] + ra[16 + 1]) + b7;
+                const float* ra = tb + (((31 & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
+                const float v = (ra[0] + ra[F67X::TW + 1]) + b7;
                 const float rr = f67_sigmoid(v);
                 const float d = xtail - rr;
                 s2 = fmaf(d, d, s2);

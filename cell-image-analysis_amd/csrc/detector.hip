@@ -8,6 +8,8 @@
 // counter-based synthetic crop generator used by the benchmark and the parity tests.
 #include "common.hpp"
 
+#include <cstring>
+
 namespace cs {
 
 namespace {
@@ -102,6 +104,143 @@ __global__ __launch_bounds__(256) void scaler_pca_kernel(
             }
             b[0] = nb[0];
             b[1] = nb[1];
+        }
+        __syncthreads();
+    }
+    // D[row = 4 kq + r (cell)][col = li (component)]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int comp = (wave + 4 * t) * 16 + li;
+        if (wave + 4 * t < ntiles && comp < C) {
+            const float mp = mean_proj[comp];
+#pragma unroll
+            for (int m = 0; m < PCA_MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long cell = cell0 + m * 16 + 4 * kq + r;
+                    if (cell < n) out[cell * C + comp] = acc[t][m][r] - mp;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- scaler + PCA on the bf16 matrix pipe
+// The same GEMM with the fp32 contraction as six bf16 products (conv45_bf16x3.hip has the algebra and the hardware check):
+// the scaled feature -- still (f - center) / scale in double, rounded once to fp32 -- is split into three bf16 terms when it
+// is staged, components_ is split on the host (pack_pca_bf16x3).  A one-hot component row reproduces the scaled feature
+// bit for bit (x1 + x2 + x3 = x exactly, every partial sum representable): the scaler test holds unchanged.
+// Staging: thread = (pair of adjacent features, 16 of the workgroup's 64 cells); a pair packs into one dword per plane, so a
+// cell's row of a plane is written as 64 consecutive dwords.  Row stride 288 B = twice an odd number of 16-byte slots.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int PX_KC = 128;                        // features per LDS chunk
+constexpr int PX_ROW = PX_KC * 2 + 32;            // bytes per cell row of a plane
+constexpr int PX_PLANE = PCA_CELLS * PX_ROW;      // 18,432 B
+constexpr int PX_LDS = 3 * PX_PLANE;              // 55,296 B
+
+__global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
+    const float* __restrict__ feat, const float* __restrict__ center, const double* __restrict__ scale,
+    const bf16x8* __restrict__ comps /* pack_pca_bf16x3 */, const float* __restrict__ mean_proj, int F, int fpad, int C,
+    int cpad, float* __restrict__ out, long n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const long cell0 = (long)blockIdx.x * PCA_CELLS;
+    const int ntiles = cpad / 16;   // <= 8: wave w owns component tiles w and w + 4
+    const int nkb = fpad / 32;
+
+    f32x4 acc[2][PCA_MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < PCA_MT; ++m) acc[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int fp = tid & 63, cg = tid >> 6;      // feature pair of the chunk, 16-cell group
+    float raw[16][2];
+    auto issue = [&](int k0) {
+        const int g0 = k0 + 2 * fp < F ? k0 + 2 * fp : F - 1, g1 = k0 + 2 * fp + 1 < F ? k0 + 2 * fp + 1 : F - 1;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const long cell = cell0 + cg * 16 + c < n ? cell0 + cg * 16 + c : n - 1;
+            raw[c][0] = feat[cell * F + g0];
+            raw[c][1] = feat[cell * F + g1];
+        }
+    };
+    auto stash = [&](int k0) {
+        const int gk = k0 + 2 * fp;
+        const bool ok0 = gk < F, ok1 = gk + 1 < F;
+        const float ctr0 = center[ok0 ? gk : 0], ctr1 = center[ok1 ? gk + 1 : 0];
+        const double scl0 = scale[ok0 ? gk : 0], scl1 = scale[ok1 ? gk + 1 : 0];
+        char* d = smem + (cg * 16) * PX_ROW + fp * 4;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const bool cok = cell0 + cg * 16 + c < n;
+            float v[2];
+            v[0] = (ok0 && cok) ? (float)((double)(raw[c][0] - ctr0) / scl0) : 0.0f;
+            v[1] = (ok1 && cok) ? (float)((double)(raw[c][1] - ctr1) / scl1) : 0.0f;
+            bf16x2 h1, h2, h3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const __bf16 a1 = (__bf16)v[j];
+                const float r1 = v[j] - (float)a1;
+                const __bf16 a2 = (__bf16)r1;
+                const float r2 = r1 - (float)a2;
+                h1[j] = a1; h2[j] = a2; h3[j] = (__bf16)r2;
+            }
+            *(bf16x2*)(d + c * PX_ROW) = h1;
+            *(bf16x2*)(d + c * PX_ROW + PX_PLANE) = h2;
+            *(bf16x2*)(d + c * PX_ROW + 2 * PX_PLANE) = h3;
+        }
+    };
+    // B fragments: [tile][k block][plane][lane][8]; a tile beyond ntiles re-reads tile 0 and is never used
+    const bf16x8* bp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = wave + 4 * t < ntiles ? wave + 4 * t : 0;
+        bp[t] = comps + (size_t)tile * nkb * 3 * 64 + lane;
+    }
+    auto load_b = [&](int kb, bf16x8 (&b)[2][3]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[t][p] = bp[t][((size_t)kb * 3 + p) * 64];
+    };
+    issue(0);
+    bf16x8 bn[2][3];
+    load_b(0, bn);
+    for (int k0 = 0; k0 < fpad; k0 += PX_KC) {
+        stash(k0);
+        __syncthreads();
+        if (k0 + PX_KC < fpad) issue(k0 + PX_KC);
+#pragma unroll
+        for (int ks = 0; ks < PX_KC / 32; ++ks) {
+            bf16x8 b[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[t][p] = bn[t][p];
+            const int kb = k0 / 32 + ks;
+            if (kb + 1 < nkb) load_b(kb + 1, bn);
+#pragma unroll
+            for (int m = 0; m < PCA_MT; ++m) {
+                const char* ap = smem + (m * 16 + li) * PX_ROW + ks * 64 + kq * 16;
+                const bf16x8 a1 = *(const bf16x8*)ap;
+                const bf16x8 a2 = *(const bf16x8*)(ap + PX_PLANE);
+                const bf16x8 a3 = *(const bf16x8*)(ap + 2 * PX_PLANE);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (wave + 4 * t < ntiles) {  // wave-uniform
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[t][2], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[t][1], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b[t][0], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[t][1], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[t][0], acc[t][m], 0, 0, 0);
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[t][0], acc[t][m], 0, 0, 0);
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -308,6 +447,58 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
     }
     hipLaunchKernelGGL(scaler_pca_kernel, dim3(grid), dim3(256), PCA_LDS, stream, feat, center, scale,
                        comps_pad, mean_proj, F, fpad, C, cpad, pca_out, (long)n_cells);
+    return hipGetLastError();
+}
+
+// components_ (zero padded [cpad][fpad] fp32) as three bf16 planes in scaler_pca_x3_kernel's B order:
+// [tile = comp / 16][k block = f / 32][plane][lane = 16 kq + li][8]: element j = plane of comps[16 tile + li][32 block + 8 kq + j]
+size_t pack_pca_bf16x3(const float* comps_pad, int cpad, int fpad, uint16_t* dst)
+{
+    const size_t n = (size_t)cpad * fpad * 3;
+    if (!dst) return n;
+    auto rne = [](float x) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &x, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto val = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float x;
+        memcpy(&x, &u, 4);
+        return x;
+    };
+    const int nkb = fpad / 32;
+    for (int c = 0; c < cpad; ++c)
+        for (int f = 0; f < fpad; ++f) {
+            const float v = comps_pad[(size_t)c * fpad + f];
+            const uint16_t w1 = rne(v);
+            const float r1 = v - val(w1);
+            const uint16_t w2 = rne(r1);
+            const float r2 = r1 - val(w2);
+            const uint16_t pl[3] = {w1, w2, rne(r2)};
+            const int tile = c >> 4, li = c & 15, kb = f >> 5, kq = (f >> 3) & 3, j = f & 7;
+            for (int p = 0; p < 3; ++p) dst[((((size_t)tile * nkb + kb) * 3 + p) * 64 + kq * 16 + li) * 8 + j] = pl[p];
+        }
+    return n;
+}
+
+hipError_t launch_scaler_pca_x3(const float* feat, const float* center, const double* scale, const uint16_t* comps_planes,
+                                const float* mean_proj, int F, int fpad, int C, int cpad, float* pca_out, int64_t n_cells,
+                                hipStream_t stream)
+{
+    if (n_cells <= 0) return hipSuccess;
+    if (cpad % 16 || cpad > 128 || fpad % PX_KC) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_cells + PCA_CELLS - 1) / PCA_CELLS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)scaler_pca_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(scaler_pca_x3_kernel, dim3(grid), dim3(256), PX_LDS, stream, feat, center, scale, (const bf16x8*)comps_planes,
+                       mean_proj, F, fpad, C, cpad, pca_out, (long)n_cells);
     return hipGetLastError();
 }
 
