@@ -417,11 +417,19 @@ def main():
         ex_tf = lambda v: v["mfma_per_cell"] * FLOP_PER_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12      # noqa: E731
         bf_tf = lambda v: v["bf16_mfma_per_cell"] * FLOP_PER_BF16_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12      # noqa: E731
         # ---- roofline: dominant kernel by device time, EXECUTED matrix-pipe FLOPs / measured duration
-        dom = max((k for k in kern if kern[k]["mfma_per_cell"] > 0 and not kern[k].get("bf16_mfma_per_cell", 0)), key=lambda k: kern[k]["ms"])
+        # a kernel's matrix work at the peaks of the pipes it runs on: seconds at peak, executed FLOP (fp32-MFMA + bf16-MFMA)
+        def at_peak(v):
+            f32 = v["mfma_per_cell"] * FLOP_PER_MFMA * v["cells"]
+            b16 = v.get("bf16_mfma_per_cell", 0) * FLOP_PER_BF16_MFMA * v["cells"]
+            return f32 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + b16 / (BF16_MFMA_PEAK_TFLOPS * 1e12), f32 + b16, b16
+        dom = max((k for k in kern if at_peak(kern[k])[1] > 0), key=lambda k: kern[k]["ms"])
         d = kern[dom]
         avg_ms = d["ms"] / d["launches"]
         cpl = d["cells"] / d["launches"]
-        ach = ex_tf(d)
+        t_pk, fl_ex, fl_b16 = at_peak(d)
+        ach = fl_ex / (d["ms"] * 1e-3) / 1e12
+        # the peak the kernel's own mix of instructions could reach: all of it fp32-MFMA -> 157.3; with bf16 MFMAs in the mix, higher
+        peak_mix = fl_ex / t_pk / 1e12
         alg = d["flops"] / (d["ms"] * 1e-3) / 1e12
         if pmc is None and not args.pmc_child:
             pmc, pmc_src = committed_pmc_traffic()
@@ -437,15 +445,19 @@ def main():
                     if sj.get("source_hash") == source_hash() and dom in sj["kernels"] and "SQ_INSTS_MFMA" in sj["kernels"][dom]:
                         per_cell = sj["kernels"][dom]["SQ_INSTS_MFMA"] / sj.get("cells_per_launch", 65536)
                         sq_check = dict(file="profiles/" + f, sq_insts_mfma_per_cell=round(per_cell, 2),
-                                        library_mfma_per_cell=d["mfma_per_cell"], equal=bool(abs(per_cell - d["mfma_per_cell"]) < 0.5))
+                                        library_mfma_per_cell=d["mfma_per_cell"] + d.get("bf16_mfma_per_cell", 0),
+                                        equal=bool(abs(per_cell - d["mfma_per_cell"] - d.get("bf16_mfma_per_cell", 0)) < 0.5))
                     break
         except Exception:  # noqa: BLE001
             pass
-        roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        executed_mfma_per_cell=d["mfma_per_cell"], executed_flop_per_launch=int(d["mfma_per_cell"] * FLOP_PER_MFMA * cpl),
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=round(peak_mix, 1), unit="TFLOP/s",
+                        frac=round(ach / peak_mix, 4),
+                        executed_mfma_per_cell=d["mfma_per_cell"], executed_bf16_mfma_per_cell=d.get("bf16_mfma_per_cell", 0),
+                        executed_flop_per_launch=int(fl_ex / d["launches"]),
+                        peak_note=("peak = executed FLOP / (fp32-MFMA FLOP / 157.3 TFLOP/s + bf16-MFMA FLOP / 2,500 TFLOP/s): the rate this kernel's "
+                                   "own instruction mix would reach with both matrix pipes at their peaks; 157.3 for a pure fp32-MFMA kernel"),
                         achieved_algorithmic=round(alg, 3), algorithmic_speedup=round(alg / ach, 4) if ach > 0 else None,
-                        note="achieved/frac price the multiply-adds the kernel executes (its MFMA count x 2,048 FLOP); achieved_algorithmic "
+                        note="achieved/frac price the multiply-adds the kernel executes (fp32 MFMAs x 2,048 FLOP + bf16 MFMAs x 16,384 FLOP); achieved_algorithmic "
                              "counts the reference graph's FLOPs of the same layers, of which Winograd / folded-upsample kernels execute a fraction",
                         sq_insts_mfma_check=sq_check,
                         traffic=traffic, traffic_unit="HBM bytes per launch", traffic_source=pmc_src,
@@ -457,6 +469,8 @@ def main():
                            tflops_executed=round(ex_tf(v), 2) if v["mfma_per_cell"] > 0 and not v.get("bf16_mfma_per_cell", 0) else None,
                            frac_executed=round(ex_tf(v) / FP32_MFMA_PEAK_TFLOPS, 4) if v["mfma_per_cell"] > 0 and not v.get("bf16_mfma_per_cell", 0) else None,
                            tflops_algorithmic=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 else None,
+                           # seconds the kernel's executed matrix work takes with both pipes at their peaks / its device time
+                           frac_matrix_peaks=round(at_peak(v)[0] / (v["ms"] * 1e-3), 4) if at_peak(v)[1] > 0 else None,
                            **({"bf16_mfma_per_cell": v["bf16_mfma_per_cell"],
                                "tflops_executed_bf16": round(bf_tf(v), 1), "frac_bf16_mfma_peak": round(bf_tf(v) / BF16_MFMA_PEAK_TFLOPS, 4)}
                               if v.get("bf16_mfma_per_cell", 0) > 0 else {}),

@@ -32,7 +32,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
-    DevBuf c12w1;          // conv1's fragments for the fused kernel (negated for filters with a negative BN scale)
+    DevBuf c12w1, c12w1x3; // conv1's fragments for the fused kernel (negated for filters with a negative BN scale); x3: its bf16 form
     DevBuf c4x3, c5x3, c6x3;   // conv4's / conv5's / conv6's weights as three bf16 planes (conv45_bf16x3.hip, conv67_x3_kernel)
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
@@ -77,6 +77,7 @@ struct cs_model {
     bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
     bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
     bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
+    bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
     bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
@@ -268,6 +269,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             tmp.resize(pack_conv12_conv1_fragments(nullptr, nullptr, nullptr));
             pack_conv12_conv1_fragments(w->kernel[l], ep.data() + cout, tmp.data());
             rc = upload(set.c12w1, tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+            std::vector<unsigned int> wx(pack_conv12_conv1_x3(nullptr, nullptr, nullptr));
+            pack_conv12_conv1_x3(w->kernel[l], ep.data() + cout, wx.data());
+            rc = upload(set.c12w1x3, wx.data(), wx.size() * sizeof(unsigned int));
             if (rc) return rc;
         }
         if (l == 1) {
@@ -488,7 +493,7 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     if (fused12)
         LAUNCH(K_CONV12_FUSED, nc,
                launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
-                                   m->act[1].as<float>(), nc, m->stream));
+                                   m->act[1].as<float>(), nc, m->stream, (m->bf16x3 && m->x3conv1) ? set.c12w1x3.as<unsigned int>() : nullptr));
     if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / A-B knob) needs p1 in HBM
         int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
         if (rc) return rc;
@@ -1173,7 +1178,7 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
             case K_CONV67_FUSED: v = (m->bf16x3 && m->x3conv6) ? 512 : 4608 + 512; break;   // conv6 phases (unless on bf16 MFMAs) + conv7's 32 -> 16 contraction
-            case K_CONV12_FUSED: v = 4608 + 1536 + 48; break;               // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct;
+            case K_CONV12_FUSED: v = (m->bf16x3 && m->x3conv1) ? 4608 : 4608 + 1536 + 48; break;   // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct (unless on bf16 MFMAs);
                                                                             // + the discarded fourth row of a cell's last 4-row batch
             case K_SCALER_PCA: v = (m->bf16x3 && m->x3pca) ? 0.0 : (double)m->fpad * m->cpad / 1024.0; break;
             default: v = 0.0;
@@ -1201,6 +1206,7 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
     }
     if (m->arch.ref) {
         if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
+        if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1) v = 66 * 8 * 3;      // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products
         if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6) v = 4.0 * 16 * 2 * 4 * 2 * 6;   // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6
     } else if (k <= K_CONV6 && m->bf16x3) {

@@ -40,8 +40,10 @@ hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, c
 size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
 // conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
 // pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
+// w1x3 (optional, pack_conv12_conv1_x3): conv1 runs on bf16 MFMAs (the three bf16 planes of the crop packed along K)
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream);
+                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3 = nullptr);
+size_t pack_conv12_conv1_x3(const float* hwio, const float* bn_scale, unsigned int* dst);     // returns 32-bit words
 size_t pack_conv12_fragments(const float* hwio, const float* bn_scale, float* dst);
 size_t pack_conv12_conv1_fragments(const float* hwio, const float* bn_scale, float* dst);
 // conv4 (layer 3) with the fp32 contraction on the bf16 matrix pipe (three-way operand split, six products): conv45_bf16x3.hip

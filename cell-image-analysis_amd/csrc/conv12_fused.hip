@@ -12,9 +12,10 @@
 // One 512-thread workgroup per CU (8 waves = 2 per SIMD, 152 KB of LDS) walks whole cells; a cell is four
 // GROUPS of 16 tiles (two tile rows = 8 conv2 rows).  Per group, four phases, one barrier after each:
 //   P1 conv1   wave (x-tile, 16-channel slice) computes the 8 new p1 rows of the group from the crop in
-//              LDS: K = 9 padded to 12 = three 16x16x4 MFMAs per 16 pixels, vertical tile pair = the pool
-//              window; bias -> ReLU -> BN -> max; rows go to a 10-slot ring in LDS (slot = row mod 10;
-//              two rows carry over to the next group).
+//              LDS: three MFMAs per 16 pixels -- bf16 ones on the crop's split-bf16 records (template flag C1X3,
+//              the default; see the kernel's comment) or 16x16x4 fp32 ones with K = 9 padded to 12 -- vertical
+//              tile pair = the pool window; bias -> ReLU -> BN -> max; rows go to a 10-slot ring in LDS (slot =
+//              row mod 10; two rows carry over to the next group).
 //   P2 V=B^TdB thread (tile, channel) transforms its 6x6 patch (scalar LDS reads, conflict-free: a half
 //              wave reads 32 consecutive channels) and writes V in the A-operand order of the MFMAs.
 //   P3 MFMA    wave (column group g of 3 transform-domain columns, 16-filter slice): U = G g G^T of its
@@ -24,11 +25,12 @@
 //              point (the ring's 8 consumed slots + a 16 KB area).
 //   P4 Y=sA    column fold of the wave's two output rows over all six columns, bias -> ReLU -> BN -> 2x2
 //              max (those two rows are one pool row), store p2.
-// LDS map: V 73,728 | ring 10 x 34 x 32 x 4 = 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008 | conv1 fragments and
-// epilogue constants 3,072.
+// LDS map: V 73,728 (its first 11.5 KB double as the crop records of the next group between P3 and P2) | ring 10 x 34 x 32 x 4 =
+// 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008 | conv1 fragments (fp32 and bf16 forms) and epilogue constants 9,344.
 #include "common.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace cs {
@@ -49,7 +51,11 @@ constexpr int OFF_INP = OFF_E2 + E2_BYTES;
 constexpr int OFF_B1 = OFF_INP + INP_BYTES;            // conv1's B fragments [2 slices][3 K steps][64 lanes]
 constexpr int OFF_EP1 = OFF_B1 + 2 * 3 * 64 * 4;       // conv1 epilogue {bias, bn scale, bn shift, sign} per channel
 constexpr int OFF_EP2 = OFF_EP1 + 32 * 16;             // conv2 epilogue, same
-constexpr int LDS_BYTES = OFF_EP2 + 64 * 16;
+constexpr int OFF_B1X = OFF_EP2 + 64 * 16;             // conv1 on bf16 MFMAs: B fragments [2 slices][3 MFMAs][64 lanes][8 bf16]
+constexpr int OFF_W9 = OFF_B1X + 2 * 3 * 64 * 16;      // ... and the fp32 weight of tap (2,2) per channel
+constexpr int LDS_BYTES = OFF_W9 + 32 * 4;
+constexpr int REC_ROWS = 20;                           // crop rows of a group as bf16 records, kept in the (then dead) V area
+static_assert(REC_ROWS * INP_STRIDE * 8 <= V_BYTES, "records live in the V area");
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_RING % 16 == 0 && OFF_E2 % 16 == 0 && OFF_INP % 16 == 0, "LDS map");
 
 __device__ __forceinline__ float vmaxf(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -98,11 +104,40 @@ __device__ __forceinline__ unsigned long long c12_stamp()
         dt = t__;                                                          \
     }
 
-template <bool DIAG>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// x -> the bf16 record [x1, x2, x3, x1] of the split-bf16 conv1 (x = x1 + x2 + x3 to 2^-24)
+__device__ __forceinline__ u32x2 c1_record(float v)
+{
+    // seven VALU instructions: v_cvt_pk_bf16_f32 rounds two floats into one dword, and the HIGH half of a dword is already the
+    // float value of that bf16 (one v_and), so each residual costs an and + a subtract
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const unsigned int d11 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)v, (__bf16)v});          // x1 | x1
+    const float r1 = v - __builtin_bit_cast(float, d11 & 0xffff0000u);
+    const unsigned int d0 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)v, (__bf16)r1});          // x1 | x2
+    const float r2 = r1 - __builtin_bit_cast(float, d0 & 0xffff0000u);
+    const unsigned int d1 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)r2, (__bf16)v});          // x3 | x1
+    return u32x2{d0, d1};
+}
+
+// C1X3: conv1 (P1) on the bf16 matrix pipe.  Its K is only 9 taps, so the three bf16 planes of the input are packed ALONG K:
+// a pixel is a 4-slot record [x1, x2, x3, x1], a K = 32 fragment is eight taps' records, and the six split products become THREE
+// MFMAs on the same A registers, one per order of magnitude: B = [w1, 0, 0, 0] per tap gives x1 w1, [w2, w1, 0, 0] gives
+// x1 w2 + x2 w1, [0, w2, w1, w3] gives x2 w2 + x3 w1 + x1 w3.  (Two MFMAs would do -- [w1, w1, w1, 0] and [w2, w2, 0, w3] -- but an
+// MFMA that sums terms 2^16 apart in ONE instruction measurably loses the small ones: p2 error 4.0e-6 of the range against
+// 2.4e-6; kept apart, the hardware's in-instruction sum only ever sees terms of one magnitude, as in the other split-bf16 kernels.)
+// A lane's fragment is two 8-byte LDS reads (the records of taps 2 kq and 2 kq + 1 of its pixel) -- no VALU.  The ninth tap
+// (2,2) is four fp32 fmas on the accumulators (lane = filter, register = pixel: the pixel's value is an LDS broadcast).
+// 48 cycles of matrix time per 16 pixels x 16 filters instead of 96, and these MFMAs leave issue slots to the pooling
+// epilogue of the SIMD's other wave.  The records of the rows a group needs are made in P4 of the previous group (the V area
+// is dead from the end of P3 to the start of P2) from the fp32 crop, which stays for the ninth tap.
+template <bool DIAG, bool C1X3>
 __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1frag,
                                                               const float* __restrict__ ep1, const float* __restrict__ ufrag,
                                                               const float* __restrict__ ep2, float* __restrict__ p2, long n_cells,
-                                                              unsigned long long* __restrict__ diag)
+                                                              unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3)
 {
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,6 +173,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         const float sc = ep2[64 + c];
         ((f32x4*)(smem + OFF_EP2))[c] = f32x4{ep2[c], sc, ep2[128 + c], sc >= 0.0f ? 1.0f : -1.0f};
     }
+    if constexpr (C1X3) {
+        for (int i = tid; i < (2 * 3 * 64 * 16 + 32 * 4) / 4; i += NTHR) ((unsigned int*)(smem + OFF_B1X))[i] = w1x3[i];
+    }
     {
         const int srow = tid >> 4, sc16 = tid & 15;
         const float* src = x + (size_t)blockIdx.x * 4096 + srow * 64 + 4 * sc16;
@@ -146,6 +184,22 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         *(f32x4*)(dst + 32 * INP_STRIDE) = *(const f32x4*)(src + 32 * 64);
     }
     __syncthreads();
+    // records of group gn's crop rows (INP rows row0 .. row0 + rows - 1: conv rows 16 gn + 2 .. 16 gn + 17 and their halo; group 0
+    // also conv rows 0, 1; the last group stops at the bottom halo row)
+    auto build_records = [&](int gn, int t) {
+        const int row0 = gn == 0 ? 0 : 16 * gn + 2;
+        const int nrec = (gn == 0 ? REC_ROWS : (gn == 3 ? 16 : 18)) * INP_STRIDE;
+        // 1,152 .. 1,440 records: two per thread and a third for some; all reads first (one LDS latency instead of three)
+        const float* src = inp + row0 * INP_STRIDE;
+        const float v0 = src[t], v1 = src[t + NTHR], v2 = src[t + 2 * NTHR < nrec ? t + 2 * NTHR : t];
+        *(u32x2*)(smem + t * 8) = c1_record(v0);
+        *(u32x2*)(smem + (t + NTHR) * 8) = c1_record(v1);
+        if (t + 2 * NTHR < nrec) *(u32x2*)(smem + (t + 2 * NTHR) * 8) = c1_record(v2);
+    };
+    if constexpr (C1X3) {
+        build_records(0, tid);
+        __syncthreads();
+    }
 
     for (long ci = 0; ci < my_cells; ++ci) {
         const long cell = blockIdx.x + ci * gridDim.x;
@@ -165,6 +219,74 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 stg0 = *(const f32x4*)src;
                 stg1 = *(const f32x4*)(src + 32 * 64);
             }
+            if constexpr (C1X3) {
+                // A fragment of lane (pixel li, kq): the records of taps 2 kq and 2 kq + 1 (tap t = (t / 3, t % 3)) of its pixel
+                const int tA = 2 * kq2, tB = 2 * kq2 + 1;
+                const int offA = ((tA / 3) * INP_STRIDE + (tA % 3) + 16 * xt + li2 + 3) * 8;
+                const int offB = ((tB / 3) * INP_STRIDE + (tB % 3) + 16 * xt + li2 + 3) * 8;
+                const bf16x8 Bx1 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 0) * 64 + l2) * 16);
+                const bf16x8 Bx2 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 1) * 64 + l2) * 16);
+                const bf16x8 Bx3 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 2) * 64 + l2) * 16);
+                const int c1 = s1 * 16 + li2;
+                const float w9 = *(const float*)(smem + OFF_W9 + c1 * 4);
+                const f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);           // bias, bn scale, bn shift, sign
+                const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
+                // tap (2,2) of the lane's four pixels 4 kq + r (D layout): crop floats (row + 2, 16 xt + 4 kq + r + 5)
+                const int off9 = 2 * INP_STRIDE + 16 * xt + 4 * kq2 + 5;
+                const int row0 = g == 0 ? 0 : 16 * g + 2;                                // first INP row of this group's records
+                auto frag = [&](int inp_row) -> bf16x8 {
+                    const char* b = smem + (inp_row - row0) * (INP_STRIDE * 8);
+                    const u32x2 ra = *(const u32x2*)(b + offA), rb = *(const u32x2*)(b + offB);
+                    return __builtin_bit_cast(bf16x8, u32x4{ra[0], ra[1], rb[0], rb[1]});
+                };
+                auto conv_row = [&](const bf16x8& a) -> f32x4 {
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx3, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx2, acc, 0, 0, 0);
+                    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx1, acc, 0, 0, 0);
+                };
+                auto tap9 = [&](f32x4& acc, int inp_row) {
+                    const float* p9 = inp + inp_row * INP_STRIDE + off9;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(p9[r], w9, acc[r]);
+                };
+                // four pooled rows at a time, in stages: all fragment reads, the 16 MFMAs, the ninth tap, the four epilogues
+                auto p1_rows4 = [&](int qb, bool last_is_zero_row) {
+                    bf16x8 a0[4], a1[4];
+                    int rr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = (i == 3 && last_is_zero_row) ? qb + 2 : qb + i;        // a valid row; its result is discarded
+                        rr[i] = 2 * (q - 1);
+                        a0[i] = frag(rr[i]);
+                        a1[i] = frag(rr[i] + 1);
+                    }
+                    f32x4 acc0[4], acc1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc0[i] = conv_row(a0[i]); acc1[i] = conv_row(a1[i]); }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { tap9(acc0[i], rr[i]); tap9(acc1[i], rr[i] + 1); }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
+                        float v0 = pool_post(acc0[i][0], acc0[i][1], acc1[i][0], acc1[i][1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        float v1 = pool_post(acc0[i][2], acc0[i][3], acc1[i][2], acc1[i][3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        if (i == 3 && last_is_zero_row) v0 = v1 = 0.0f;                     // q = 33: the bottom zero row
+                        row[0] = v0;
+                        row[32] = v1;
+                    }
+                };
+                if (g == 0) {
+                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
+                    f32x4 acc0 = conv_row(frag(0)), acc1 = conv_row(frag(1));                      // q = 1: conv rows 0, 1
+                    tap9(acc0, 0);
+                    tap9(acc1, 1);
+                    float* const row = ring + RING_ROWF + pwoff;
+                    row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                    row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                }
+                p1_rows4(8 * g + 2, false);
+                p1_rows4(8 * g + 6, g == 3);
+            } else
             {
                 // conv1 A operand: lane (pixel li, k = 4 s + kq) reads tap (k / 3, k % 3); the padded taps k >= 9 carry zero
                 // weights and read tap 0 (finite whenever the true taps are)
@@ -374,6 +496,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 };
                 if (gcol == 0) finish(std::true_type{});
                 else finish(std::false_type{});
+                if constexpr (C1X3) {      // V is dead until the next P2: the next group's records (g = 3: the next cell's crop is in place since P2)
+                    if (g < 3 || has_next) build_records(g < 3 ? g + 1 : 0, t2);
+                }
             }
             C12_STAMP(6)
             __syncthreads();   // the exchange area inside the ring is consumed before the next P1 refills those slots
@@ -434,19 +559,60 @@ size_t pack_conv12_conv1_fragments(const float* hwio /* [3][3][1][32] */, const 
     return total;
 }
 
+// conv1 for the bf16 form of P1 (C1X3): per (slice, MFMA m, lane (li, kq)) eight bf16 = the B slots of taps 2 kq and 2 kq + 1
+// against the records [x1, x2, x3, x1]: m = 0: [w1, 0, 0, 0], m = 1: [w2, w1, 0, 0], m = 2: [0, w2, w1, w3] (w = w1 + w2 + w3, bf16 each; negated for the
+// filters with a negative BN scale, as above); then the fp32 weights of tap (2,2) per channel.  Returns 32-bit words.
+size_t pack_conv12_conv1_x3(const float* hwio /* [3][3][1][32] */, const float* bn_scale /* [32] */, unsigned int* dst)
+{
+    const size_t total = (size_t)(2 * 3 * 64 * 16 + 32 * 4) / 4;
+    if (!dst) return total;
+    auto rne = [](float v) -> unsigned short {
+        unsigned int u;
+        memcpy(&u, &v, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    };
+    auto val = [](unsigned short h) -> float {
+        const unsigned int u = (unsigned int)h << 16;
+        float v;
+        memcpy(&v, &u, 4);
+        return v;
+    };
+    unsigned short* d16 = (unsigned short*)dst;
+    for (int nsl = 0; nsl < 2; ++nsl)
+        for (int m = 0; m < 3; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int li = lane & 15, kq = lane >> 4, tap = 2 * kq + (j >> 2), slot = j & 3, co = nsl * 16 + li;
+                    float w = hwio[(size_t)tap * 32 + co];
+                    if (bn_scale[co] < 0.0f) w = -w;
+                    const unsigned short w1 = rne(w);
+                    const float r1 = w - val(w1);
+                    const unsigned short w2 = rne(r1);
+                    const unsigned short w3 = rne(r1 - val(w2));
+                    const unsigned short tab[3][4] = {{w1, 0, 0, 0}, {w2, w1, 0, 0}, {0, w2, w1, w3}};
+                    d16[(((size_t)nsl * 3 + m) * 64 + lane) * 8 + j] = tab[m][slot];
+                }
+    float* w9 = (float*)(dst + (2 * 3 * 64 * 16) / 4);
+    for (int co = 0; co < 32; ++co) w9[co] = bn_scale[co] < 0.0f ? -hwio[(size_t)8 * 32 + co] : hwio[(size_t)8 * 32 + co];
+    return total;
+}
+
 unsigned long long* g_c12_diag = nullptr;
 int g_c12_diag_blocks = 0;
 
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream)
+                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3)
 {
     static int cus = 0;
     static const bool diag = getenv("CS_C12_DIAG") != nullptr;
     if (!cus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv12_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
+        hipError_t e;
+#define C12_ATTR(D, X)                                                                                                              \
+    if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<D, X>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
+        C12_ATTR(false, false); C12_ATTR(true, false); C12_ATTR(false, true); C12_ATTR(true, true);
+#undef C12_ATTR
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -458,12 +624,13 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
     }
     if (n_cells <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);      // one workgroup per CU (LDS-bound), persistent over cells
-    if (diag)
-        hipLaunchKernelGGL(conv12_fused_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2, (long)n_cells,
-                           g_c12_diag);
-    else
-        hipLaunchKernelGGL(conv12_fused_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2, (long)n_cells,
-                           (unsigned long long*)nullptr);
+    unsigned long long* const dp = diag ? g_c12_diag : nullptr;
+#define C12_GO(D, X)                                                                                                                \
+    hipLaunchKernelGGL((conv12_fused_kernel<D, X>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2,       \
+                       (long)n_cells, dp, w1x3)
+    if (w1x3) { if (diag) C12_GO(true, true); else C12_GO(false, true); }       // conv1 on bf16 MFMAs
+    else      { if (diag) C12_GO(true, false); else C12_GO(false, false); }
+#undef C12_GO
     return hipGetLastError();
 }
 

@@ -65,25 +65,26 @@ def test_each_layer_against_oracle(engine, weights, crops, layer):
 
 def test_conv4_split_bf16_contraction_is_in_the_fp32_error_class(weights, crops, monkeypatch):
     """conv4 takes its fp32 contraction on the bf16 matrix pipe (three-way operand split, six products:
-    csrc/conv45_bf16x3.hip).  Both kernels -- that one and the fp32-MFMA one behind CS_NO_BF16X3 -- are compared
-    with a float64 conv of the SAME p3 (the device's own, bit-identical for both), so only conv4's arithmetic is
-    in the error: both must sit at fp32 rounding level, far inside the 1e-5 layer tolerance."""
-    e = Engine.from_weights(weights)
-    p3, a4 = e.layer_output(crops, 2), e.layer_output(crops, 3)
-    e.close()
-    monkeypatch.setenv("CS_NO_BF16X3", "1")
-    e = Engine.from_weights(weights)
-    assert np.array_equal(e.layer_output(crops, 2), p3)
-    b4 = e.layer_output(crops, 3)
-    e.close()
-    assert not np.array_equal(a4, b4)                      # the knob really switches kernels
+    csrc/conv45_bf16x3.hip).  That kernel and the fp32-MFMA one behind CS_NO_BF16X3 are each compared with a float64
+    conv of the p3 the SAME engine produced, so only conv4's arithmetic is in the error: both must sit at fp32
+    rounding level, far inside the 1e-5 layer tolerance."""
     k = weights.kernels[3].astype(np.float64)
-    xp = np.pad(p3.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
-    z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 8, dx:dx + 8, :], k[dy, dx]) for dy in range(3) for dx in range(3))
     s = weights.bn_gamma[3].astype(np.float64) / np.sqrt(weights.bn_var[3].astype(np.float64) + weights.bn_eps)
-    ref = np.maximum(z + weights.biases[3], 0.0) * s + (weights.bn_beta[3] - weights.bn_mean[3] * s)
-    ea = H.assert_close_scaled(a4, ref, 2e-6, "conv4, split-bf16 contraction")
-    eb = H.assert_close_scaled(b4, ref, 2e-6, "conv4, fp32 matrix instructions")
+
+    def conv4_error(what):
+        e = Engine.from_weights(weights)
+        p3, a4 = e.layer_output(crops, 2), e.layer_output(crops, 3)
+        bf16 = e.profile()["conv4_relu_bn"]["bf16_mfma_per_cell"]
+        e.close()
+        xp = np.pad(p3.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 8, dx:dx + 8, :], k[dy, dx]) for dy in range(3) for dx in range(3))
+        ref = np.maximum(z + weights.biases[3], 0.0) * s + (weights.bn_beta[3] - weights.bn_mean[3] * s)
+        return H.assert_close_scaled(a4, ref, 2e-6, what), bf16, a4
+
+    ea, bfa, a4 = conv4_error("conv4, split-bf16 contraction")
+    monkeypatch.setenv("CS_NO_BF16X3", "1")
+    eb, bfb, b4 = conv4_error("conv4, fp32 matrix instructions")
+    assert bfa == 432 and bfb == 0 and not np.array_equal(a4, b4)          # the knob really switches kernels
     print(f"conv4 max err / max|ref|: split-bf16 {ea:.3e}, fp32 MFMA {eb:.3e}")
 
 
@@ -370,7 +371,8 @@ def test_automatic_chunk_by_input_kind(weights, det):
 
 def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
     """conv1 + conv2 run as ONE kernel (conv12_fused.hip: conv2 as Winograd F(4x4,3x3), p1 rows produced into an LDS ring and
-    never written to HBM) whenever p1 itself is not asked for.  Every element of p2 -- 600 cells = more than two cells per
+    never written to HBM; conv1 inside it on bf16 MFMAs with the input's three bf16 planes packed along K, or on fp32 MFMAs
+    behind CS_NO_BF16X3_CONV1=1) whenever p1 itself is not asked for.  Every element of p2 -- 600 cells = more than two cells per
     persistent workgroup (256 CUs x 1), so the ring wrap between cells, the crop prefetch and every workgroup are
     covered -- against the fp64-evaluated oracle at the layer bar, and against the two-kernel path (CS_NO_FUSE12=1:
     conv1 kernel -> p1 in HBM -> F(2x2,3x3) conv2).  p1 of the stand-alone conv1 kernel (what layer_output(0) and
@@ -389,17 +391,27 @@ def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
         e2 = Engine.from_weights(weights)
     finally:
         del os.environ["CS_NO_FUSE12"]
+    os.environ["CS_NO_BF16X3_CONV1"] = "1"                 # the fused kernel with conv1 on the fp32 matrix instructions
+    try:
+        e3 = Engine.from_weights(weights)
+    finally:
+        del os.environ["CS_NO_BF16X3_CONV1"]
     try:
         p1 = e.layer_output(x, 0)
         p2 = e.layer_output(x, 1)
         p2_two = e2.layer_output(x, 1)
+        p2_c1f32 = e3.layer_output(x, 1)
+        assert e.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 1584 and e3.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 0
     finally:
-        e.close(); e2.close()
+        e.close(); e2.close(); e3.close()
     s1, s2 = np.abs(ref[0]).max(), np.abs(ref[1]).max()
     e1 = np.abs(p1.astype(np.float64) - ref[0]).max(axis=(1, 2, 3)) / s1
     ef = np.abs(p2.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
     et = np.abs(p2_two.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
-    print("p1 max err / range %.2e; p2 fused %.2e (worst cell %d), two-kernel %.2e" % (e1.max(), ef.max(), int(ef.argmax()), et.max()))
+    e3f = np.abs(p2_c1f32.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
+    print("p1 max err / range %.2e; p2 fused %.2e (worst cell %d), fused with conv1 on fp32 MFMAs %.2e, two-kernel %.2e"
+          % (e1.max(), ef.max(), int(ef.argmax()), e3f.max(), et.max()))
+    assert e3f.max() <= 1e-5 and not np.array_equal(p2, p2_c1f32)
     assert e1.max() <= 1e-5, f"conv1: cell {int(e1.argmax())}"
     assert et.max() <= 1e-5
     assert ef.max() <= 1e-5, f"fused conv1+conv2: cell {int(ef.argmax())} off by {ef.max():.3e} of the range"

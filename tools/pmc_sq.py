@@ -35,8 +35,8 @@ def main():
             for k, counters in by.items():
                 if pat not in k:
                     continue
-                if "x3_kernel" in pat:
-                    x3.add(name)
+                if "x3_kernel" in pat or ("conv12_fused_kernel" in pat and ", true>" in k):
+                    x3.add(name)      # conv12_fused_kernel<DIAG, C1X3 = true>: conv1 on bf16 MFMAs
                 for c, v in counters.items():
                     longest = max(x[1] for x in v)
                     full = [x for x in v if x[1] > 0.7 * longest]
@@ -45,9 +45,10 @@ def main():
     for name, c in out.items():
         if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c:
             if name in x3:
-                # bf16 MFMAs: 16 cycles each; the fused conv6 + conv7 kernel also issues 512 fp32 MFMAs (32 cycles) per cell
-                f32 = 512 * 65536 if name == "conv6_conv7_fused_err" else 0
-                c["mfma_kind"] = "v_mfma_f32_16x16x32_bf16" + (" + 512 v_mfma_f32_16x16x4_f32 per cell" if f32 else "")
+                # bf16 MFMAs: 16 cycles each; the two fused kernels also issue fp32 MFMAs (32 cycles): conv7's contraction / conv2
+                per_cell_f32 = {"conv6_conv7_fused_err": 512, "conv1_conv2_fused": 4608}.get(name, 0)
+                f32 = per_cell_f32 * 65536
+                c["mfma_kind"] = "v_mfma_f32_16x16x32_bf16" + (" + %d v_mfma_f32_16x16x4_f32 per cell" % per_cell_f32 if f32 else "")
                 c["simd_cycles_mfma"] = 16 * (c["SQ_INSTS_MFMA"] - f32) + 32 * f32
                 c["mfma_util_at_2p1_ghz"] = round(c["simd_cycles_mfma"] / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3 * 2.1e9), 3)
                 continue
