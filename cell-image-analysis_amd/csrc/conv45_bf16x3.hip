@@ -4,12 +4,15 @@
 // x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), each residual exact in fp32) and the product
 // a*b is taken as the six partial products of weight 2^0 .. 2^-16
 //      a1 b1 | a1 b2, a2 b1 | a1 b3, a2 b2, a3 b1
-// (each exact in the MFMA's fp32 accumulator; the three dropped ones are below 2^-24 of |a b|).
+// (each product exact in fp32; the three dropped ones are below 2^-24 of |a b|).  One MFMA carries ONE of these
+// magnitudes: measured on the MI355X (conv1 in conv12_fused.hip), an MFMA that sums terms 2^16 apart inside one
+// instruction loses part of the small ones.
 // v_mfma_f32_16x16x32_bf16 does 16,384 multiply-adds in ~16 cycles where v_mfma_f32_16x16x4_f32 does 1,024 in
 // 32, so six of them per 32 channels cost 96 cycles against 256: the contraction runs 2.7x faster at the same
 // fp32 error class (tests/study_split_bf16.py; measured against the oracle by tests/test_gpu_parity.py at the
-// unchanged tolerances).  This layer is the hardware proof of the technique on a small, self-contained conv;
-// DESIGN.md section 8 discusses it for conv2.
+// unchanged tolerances).  This layer was the hardware proof of the technique (conv4 against a float64 conv of the
+// same p3: 2.4e-7 of the range, the fp32 MFMA chain 8.0e-7); DESIGN.md section 3g lists where else it runs and why
+// the Winograd layers keep the fp32 instructions.
 //
 // Mapping (D[16 pixels][16 couts] += A[16 pixels][32 ch] * B[32 ch][16 couts], one MFMA per tap and product):
 //   lane l: A = 8 channels 8(l>>4)..+7 of pixel l&15 of the tile (two rows of eight), B = the same 8 channels of
