@@ -88,6 +88,20 @@ def test_conv4_split_bf16_contraction_is_in_the_fp32_error_class(weights, crops,
     print(f"conv4 max err / max|ref|: split-bf16 {ea:.3e}, fp32 MFMA {eb:.3e}")
 
 
+@pytest.mark.parametrize("n", [1, 3, 769, 1537])
+def test_bottleneck_split_bf16_kernels_at_odd_cell_counts(weights, n):
+    """conv4 / conv5 (csrc/conv45_bf16x3.hip) are persistent workgroups that prefetch the next cell while one is in the matrix
+    phase: counts below, at and past their resident grids (2 and 1 workgroups per CU x 256 CUs) against the oracle."""
+    x = synth.synth_crops(23, 4242, n)
+    ref = oracle.cae_forward(weights, x, acc64=True, layers=True)["layers"]
+    e = Engine.from_weights(weights)
+    try:
+        for l in (3, 4):
+            H.assert_close_scaled(e.layer_output(x, l), ref[l], 1e-5, f"layer {l}, {n} cells")
+    finally:
+        e.close()
+
+
 def test_golden_cae_vectors(golden_cae):
     g = golden_cae
     e = Engine.from_weights(H.cae_from_golden(g))
