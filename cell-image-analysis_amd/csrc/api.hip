@@ -33,7 +33,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf c12w1, c12w1x3; // conv1's fragments for the fused kernel (negated for filters with a negative BN scale); x3: its bf16 form
-    DevBuf c4x3, c5x3, c6x3;   // conv4's / conv5's / conv6's weights as three bf16 planes (conv45_bf16x3.hip, conv67_x3_kernel)
+    DevBuf c3x3, c4x3, c5x3, c6x3;   // conv3's Winograd U / conv4's / conv5's / conv6's weights as three bf16 planes
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -77,6 +77,7 @@ struct cs_model {
     bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
     bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
     bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
+    bool x3conv3 = getenv("CS_NO_BF16X3_CONV3") == nullptr; // A/B knob: conv3's Winograd contraction on the fp32 matrix instructions
     bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
     bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
@@ -241,6 +242,12 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             tmp.resize(pack_wino_cs_fragments(l, nullptr, nullptr));
             pack_wino_cs_fragments(l, w->kernel[l], tmp.data());
             rc = upload(set.winocs[l], tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+        }
+        if (l == 2) {
+            std::vector<uint16_t> planes(pack_wino3_x3(nullptr, nullptr));
+            pack_wino3_x3(w->kernel[l], planes.data());
+            rc = upload(set.c3x3, planes.data(), planes.size() * sizeof(uint16_t));
             if (rc) return rc;
         }
         if (l == 3) {
@@ -508,6 +515,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_up(l, in, set.winoup[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
+        if (l == 2 && m->wino3 && m->use_wino && m->bf16x3 && m->x3conv3) {
+            LAUNCH(K_CONV3, nc,
+                   launch_conv3_wino_x3(in, set.c3x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
         if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
@@ -1173,7 +1185,7 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
         switch (k) {
             case K_CONV1: v = 1536; break;                                  // 256 tiles x 2 slices x 3 K steps
             case K_CONV2: v = wn ? 8192 : 18432; break;                     // F(2x2,3x3): 16 points x 16 groups x 8 x 4
-            case K_CONV3: v = (wn && m->wino3) ? 2048 : 4608; break;
+            case K_CONV3: v = (wn && m->wino3) ? ((m->bf16x3 && m->x3conv3) ? 0 : 2048) : 4608; break;
             case K_CONV4: v = m->bf16x3 ? 0 : 576; break;                   // split-bf16: 432 v_mfma_f32_16x16x32_bf16, a different instruction and peak -- not counted here
             case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
@@ -1206,6 +1218,7 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
     }
     if (m->arch.ref) {
         if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
+        if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3) v = 16.0 * 4 * 2 * 2 * 6;   // 16 points x 4 tile groups x 2 slices x 2 blocks x 6
         if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1) v = 66 * 8 * 3;      // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products
         if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6) v = 4.0 * 16 * 2 * 4 * 2 * 6;   // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6

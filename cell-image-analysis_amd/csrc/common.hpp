@@ -38,6 +38,9 @@ size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* d
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
 size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
+// conv3 (layer 2) in the same Winograd form with the contraction on the bf16 matrix pipe (six split products), one wave per SIMD
+hipError_t launch_conv3_wino_x3(const float* in, const uint16_t* uplanes, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+size_t pack_wino3_x3(const float* hwio, uint16_t* dst);       // returns the number of bf16 values
 // conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
 // pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
 // w1x3 (optional, pack_conv12_conv1_x3): conv1 runs on bf16 MFMAs (the three bf16 planes of the crop packed along K)

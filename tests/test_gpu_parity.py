@@ -88,6 +88,30 @@ def test_conv4_split_bf16_contraction_is_in_the_fp32_error_class(weights, crops,
     print(f"conv4 max err / max|ref|: split-bf16 {ea:.3e}, fp32 MFMA {eb:.3e}")
 
 
+def test_conv3_winograd_on_bf16_mfmas_is_in_the_fp32_error_class(weights, crops, monkeypatch):
+    """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs on bf16 MFMAs by default (conv3_wino_x3_kernel) and
+    on fp32 MFMAs behind CS_NO_BF16X3_CONV3=1: each against a float64 conv + ReLU + BN + max-pool of the p2 the SAME engine made."""
+    k = weights.kernels[2].astype(np.float64)
+    s = weights.bn_gamma[2].astype(np.float64) / np.sqrt(weights.bn_var[2].astype(np.float64) + weights.bn_eps)
+
+    def conv3_error(what):
+        e = Engine.from_weights(weights)
+        p2, p3 = e.layer_output(crops, 1), e.layer_output(crops, 2)
+        bf16 = e.profile()["conv3_relu_bn_pool"]["bf16_mfma_per_cell"]
+        e.close()
+        xp = np.pad(p2.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 16, dx:dx + 16, :], k[dy, dx]) for dy in range(3) for dx in range(3))
+        a = np.maximum(z + weights.biases[2], 0.0) * s + (weights.bn_beta[2] - weights.bn_mean[2] * s)
+        ref = a.reshape(len(a), 8, 2, 8, 2, 32).max(axis=(2, 4))
+        return H.assert_close_scaled(p3, ref, 3e-6, what), bf16, p3
+
+    ea, bfa, a3 = conv3_error("conv3, Winograd on bf16 MFMAs")
+    monkeypatch.setenv("CS_NO_BF16X3_CONV3", "1")
+    eb, bfb, b3 = conv3_error("conv3, Winograd on fp32 MFMAs")
+    assert bfa == 1536 and bfb == 0 and not np.array_equal(a3, b3)
+    print(f"conv3 max err / max|ref|: bf16 MFMAs {ea:.3e}, fp32 MFMAs {eb:.3e}")
+
+
 @pytest.mark.parametrize("n", [1, 3, 769, 1537])
 def test_bottleneck_split_bf16_kernels_at_odd_cell_counts(weights, n):
     """conv4 / conv5 (csrc/conv45_bf16x3.hip) are persistent workgroups that prefetch the next cell while one is in the matrix
