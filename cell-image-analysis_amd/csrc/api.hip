@@ -307,6 +307,12 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
             std::vector<float> wf(pack_generic_folded(cin, cout, nullptr, nullptr));
             pack_generic_folded(cin, cout, w->kernel[l], wf.data());
             if ((rc = upload(set.wf[l], wf.data(), wf.size() * sizeof(float)))) return rc;
+            if (l == a.n_conv - 1 && cout == 1 && conv_last_x3_takes(a.gh[l], a.gw[l], cin)) {
+                std::vector<uint16_t> pl(pack_last_bf16x3(cin, nullptr, nullptr));
+                pack_last_bf16x3(cin, wf.data(), pl.data());
+                if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
+                set.x3[l] = true;
+            }
             if (l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 1)) {
                 std::vector<uint16_t> pl(pack_generic_bf16x3(16, cin, cout, nullptr, nullptr));
                 pack_generic_bf16x3(16, cin, cout, wf.data(), pl.data());
@@ -473,6 +479,12 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
         float* out = is_last ? (recon ? recon : m->recon.as<float>()) : m->act[l].as<float>();
         const int epi = is_last ? GEN_EPI_SIGMOID : (l < a.n_enc ? GEN_EPI_BN_POOL : GEN_EPI_BN);
         const int kid = l < 6 ? K_CONV1 + l : K_CONV7_ERR;       // profile bucket: by position
+        if (set.x3[l] && m->bf16x3 && is_last) {
+            LAUNCH(kid, nc,
+                   launch_conv_last_x3(in, set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), m->stream));
+            LAUNCH(K_CONV7_ERR, nc, launch_recon_err(out, x, nc, (int)a.npix, m->errpart.as<float>(), m->stream));
+            continue;
+        }
         if (set.x3[l] && m->bf16x3) {
             LAUNCH(kid, nc,
                    launch_conv_generic_x3(in, set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],

@@ -128,6 +128,12 @@ int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups);
 size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_t* dst);     // returns the number of bf16 values
 hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
                                   int cout, int ups, int epi, hipStream_t stream);
+// the 1-filter sigmoid conv behind an UpSampling2D as a cin -> 16 GEMM on bf16 MFMAs + a gather (cin 32 or 64):
+// wplanes = pack_last_bf16x3(cin, pack_generic_folded(cin, 1, hwio, .), .); out = the reconstruction [n][H][W]
+int conv_last_x3_takes(int H, int W, int cin);
+size_t pack_last_bf16x3(int cin, const float* weff, uint16_t* dst);
+hipError_t launch_conv_last_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
+                               hipStream_t stream);
 int conv_generic_folds(int H, int W, int cin, int cout);
 // run-time-shaped training kernels (train_generic.hip)
 hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s);

@@ -254,6 +254,77 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
     }
 }
 
+// ---- the 1-filter last conv behind an UpSampling2D (cout = 1, sigmoid) on the matrix pipe ---------------------------------------
+// conv_generic.hip runs it on the vector ALU (16 x cin multiply-adds per stored pixel).  As in the reference graph's fused
+// conv6 + conv7 kernel, contracting the channels FIRST turns it into a GEMM with a full N: with the folded kernels
+// W_eff[n = (a 2 + b) 4 + (ry 2 + rx)][c] (pack_generic_folded with cout = 1),
+//     T[pixel][n] = sum_c a[pixel][c] W_eff[n][c]                  one six-MFMA chain per 16 staged pixels and 32 channels
+//     out(2y + a, 2x + b) = sigmoid(b7 + sum_{ry,rx} T[(y + a - 1 + ry, x + b - 1 + rx)][n(a, b, ry, rx)])      4 LDS reads per output
+// The strip (SRS stored rows + halo, flattened: T is per pixel, so tiles may wrap rows) is staged as three bf16 planes; T lives in
+// LDS n-major with a pitch = 4 (mod 8) floats, which keeps the gather's 32 lanes (16 columns x 2 column phases) on 31 banks.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv_last_x3_kernel(const float* __restrict__ in, const bf16x8* __restrict__ wpl,
+                                                           const float* __restrict__ ep, float* __restrict__ out, long n, int H, int W,
+                                                           int SRS, int NT /* 16-pixel tiles per strip */, int P /* T pitch */)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    constexpr int psb = 6 * CIN + 32, PB = 2 * CIN, nkb = CIN / 32, c4n = CIN / 4;
+    const int Hs = H / 2, Ws = W / 2, R = SRS + 2, WP = Ws + 2, NPX = R * WP;
+    float* const T = (float*)(smem + (size_t)NT * 16 * psb);
+    bf16x8 B[nkb][3];
+#pragma unroll
+    for (int kb = 0; kb < nkb; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) B[kb][p] = wpl[(kb * 3 + p) * 64 + lane];
+    const float bias = ep[0];
+    for (int i = tid; i < NT * 16 * psb / 16; i += 512) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // pad pixels stay zero
+    const int nstrip = Hs / SRS;
+    for (long item = blockIdx.x; item < n * nstrip; item += gridDim.x) {
+        const int ys0 = (int)(item % nstrip) * SRS;
+        const long cell = item / nstrip;
+        const float* src = in + (size_t)cell * Hs * Ws * CIN;
+        __syncthreads();                                  // the previous item's gather is done with T; its tiles with the strip
+        for (int e = tid; e < NPX * c4n; e += 512) {
+            const int c4 = e % c4n, pix = e / c4n;
+            const int r = pix / WP, c = pix - r * WP;
+            const int sy = ys0 - 1 + r, sx = c - 1;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * CIN + 4 * c4);
+            bf16x4 h1, h2, h3;
+            split4(v, h1, h2, h3);
+            char* d = smem + pix * psb + c4 * 8;
+            *(bf16x4*)d = h1;
+            *(bf16x4*)(d + PB) = h2;
+            *(bf16x4*)(d + 2 * PB) = h3;
+        }
+        __syncthreads();
+        for (int t = wave; t < NT; t += 8) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const char* ap = smem + (16 * t + li) * psb + kq * 16;
+#pragma unroll
+            for (int kb = 0; kb < nkb; ++kb) {
+                const bf16x8 a[3] = {*(const bf16x8*)(ap + kb * 64), *(const bf16x8*)(ap + kb * 64 + PB), *(const bf16x8*)(ap + kb * 64 + 2 * PB)};
+                acc = mac6(a, B[kb], acc);
+            }
+            // D: lane = n, registers = pixels 16 t + 4 kq + r
+            *(f32x4*)(T + li * P + 16 * t + 4 * kq) = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * SRS * W; idx += 512) {
+            const int Yl = idx / W, X = idx - Yl * W;
+            const int ys = Yl >> 1, a = Yl & 1, xs = X >> 1, b = X & 1;
+            // stored (ys0 + ys + a - 1 + ry, xs + b - 1 + rx) = staged (ys + a + ry, xs + b + rx); n = ((a 2 + b) 2 + ry) 2 + rx
+            const float* t0 = T + ((a * 2 + b) * 4) * P + (ys + a) * WP + xs + b;
+            const float s0 = t0[0] + t0[P + 1];
+            const float s1 = t0[2 * P + WP] + t0[3 * P + WP + 1];
+            const float z = (s0 + s1) + bias;
+            out[((size_t)cell * H + 2 * ys0 + Yl) * W + X] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
 uint16_t bf16_rne(float x)
 {
     uint32_t u;
@@ -389,6 +460,74 @@ hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, cons
 #undef X3_TPW
 #undef X3_LAUNCH
     if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// the last conv: plan (stored rows per strip, tiles, T pitch, LDS bytes) or false
+static bool last_x3_plan(int H, int W, int cin, int* SRS, int* NT, int* P, size_t* lds)
+{
+    static const bool off = getenv("CS_NO_BF16X3") != nullptr || getenv("CS_GENERIC_V1") != nullptr || getenv("CS_GENERIC_NO_FOLD") != nullptr;
+    if (off || !(cin == 32 || cin == 64) || H % 2 || W % 2) return false;
+    const int Hs = H / 2, Ws = W / 2, psb = 6 * cin + 32;
+    for (int srs = 8; srs >= 1; srs /= 2) {
+        if (Hs % srs) continue;
+        const int npx = (srs + 2) * (Ws + 2), nt = (npx + 15) / 16, p = ((nt * 16 + 7) & ~7) + 4;
+        const size_t bytes = (size_t)nt * 16 * psb + (size_t)16 * p * sizeof(float);
+        if (bytes > 150 * 1024) continue;
+        *SRS = srs; *NT = nt; *P = p; *lds = bytes;
+        return true;
+    }
+    return false;
+}
+
+int conv_last_x3_takes(int H, int W, int cin)
+{
+    int SRS, NT, P;
+    size_t lds;
+    return last_x3_plan(H, W, cin, &SRS, &NT, &P, &lds) ? 1 : 0;
+}
+
+// weff: pack_generic_folded(cin, 1, ...) = W_eff[n = phase 4 + tap][c]; dst: [block][plane][lane = 16 kq + n][8]
+size_t pack_last_bf16x3(int cin, const float* weff, uint16_t* dst)
+{
+    const int nkb = cin / 32;
+    const size_t total = (size_t)nkb * 3 * 64 * 8;
+    if (!dst) return total;
+    for (int kb = 0; kb < nkb; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int nn = l & 15, kq = l >> 4;
+                const float v = weff[(size_t)nn * cin + 32 * kb + 8 * kq + j];
+                const uint16_t w1 = bf16_rne(v);
+                const float r1 = v - bf16_val(w1);
+                const uint16_t w2 = bf16_rne(r1);
+                const uint16_t pl[3] = {w1, w2, bf16_rne(r1 - bf16_val(w2))};
+                for (int p = 0; p < 3; ++p) dst[(((size_t)kb * 3 + p) * 64 + l) * 8 + j] = pl[p];
+            }
+    return total;
+}
+
+hipError_t launch_conv_last_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
+                               hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    int SRS = 0, NT = 0, P = 0;
+    size_t lds = 0;
+    if (!last_x3_plan(H, W, cin, &SRS, &NT, &P, &lds)) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long items = (long)n * ((H / 2) / SRS);
+    const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+    const unsigned grid = (unsigned)(items < (long)cus * per_cu ? items : (long)cus * per_cu);
+    hipError_t e;
+    if (cin == 32) {
+        if ((e = hipFuncSetAttribute((const void*)conv_last_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_last_x3_kernel<32>, dim3(grid), dim3(512), lds, stream, in, (const bf16x8*)wplanes, ep, out, (long)n, H, W, SRS, NT, P);
+    } else {
+        if ((e = hipFuncSetAttribute((const void*)conv_last_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_last_x3_kernel<64>, dim3(grid), dim3(512), lds, stream, in, (const bf16x8*)wplanes, ep, out, (long)n, H, W, SRS, NT, P);
+    }
     return hipGetLastError();
 }
 
