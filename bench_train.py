@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cells", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", action="store_true",
+                    help="BASELINE.json configs[4]'s architecture instead: 128x128 crops, filters 32-64-128 | 128-64-32-1 (generic trainer)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -48,10 +50,14 @@ def main():
     from cellscreen.trainer import Trainer
 
     n_train = int(args.cells * 0.8)
-    X = torch.from_numpy(synth.blob_crops(42 + rank, min(n_train, 4096))).to(dev)   # structured crops; reused cyclically
+    hw, ch, n_enc = ((128, 128), (32, 64, 128, 128, 64, 32, 1), 3) if args.variant else ((64, 64), (32, 64, 32, 32, 64, 32, 1), 3)
+    flop_step = 3 * 2 * 349.18e6 if args.variant else FLOP_PER_CELL_STEP
+    if args.variant:
+        n_train = min(n_train, 4096)
+    X = torch.from_numpy(synth.blob_crops(42 + rank, min(n_train, 4096), hw=hw)).to(dev)   # structured crops; reused cyclically
     reps = (n_train + len(X) - 1) // len(X)
     X = X.repeat(reps, 1, 1)[:n_train].contiguous()
-    tr = Trainer(synth.random_cae(seed=42, trivial_bn=True), device_id=local_rank)
+    tr = Trainer(synth.random_cae(seed=42, hw=hw, channels=ch, n_enc=n_enc, trivial_bn=True), device_id=local_rank)
     g = torch.zeros(tr.n_trainable, dtype=torch.float32, device=dev)
     if world > 1:
         tr.use_grad_tensor(g)
@@ -90,12 +96,14 @@ def main():
         line = {"metric": "cells/sec trained (CAE fwd+bwd+Adam, batch 32, fp32)", "value": round(cells / el, 1), "unit": "cells/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "BASELINE.json configs[1]: CAE training on 50k synthetic 64x64 crops (40k train), batch %d per GPU" % args.batch,
+                "config": {"workload": ("BASELINE.json configs[4] architecture (128x128, filters 32-64-128 | 128-64-32-1): generic trainer, batch %d per GPU" % args.batch)
+                                       if args.variant else
+                                       "BASELINE.json configs[1]: CAE training on 50k synthetic 64x64 crops (40k train), batch %d per GPU" % args.batch,
                            "batch_per_gpu": args.batch, "steps_per_epoch": n_train // args.batch, "parallelism": "dp%d" % world},
-                "tflops_algorithmic": round(cells / el * FLOP_PER_CELL_STEP / 1e12 / world, 3),
+                "tflops_algorithmic": round(cells / el * flop_step / 1e12 / world, 3),
                 "epoch_seconds_at_1250_steps": round(el / args.steps * 1250, 3),
                 "loss_first_last": [round(first, 6), round(last, 6)]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.variant:
             from oracle import train_oracle as T
             st = T.TrainState(synth.random_cae(seed=42, trivial_bn=True), dtype=np.float32)
             xb = X[:args.batch].cpu().numpy()
