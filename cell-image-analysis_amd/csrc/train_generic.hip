@@ -13,6 +13,8 @@
 // cs_train_forward_backward -> all-reduce -> cs_train_apply) is what BASELINE.json configs[4] needs from it.
 #include "train_internal.hpp"
 
+#include <cstdlib>
+
 #include <vector>
 
 using namespace cs;
@@ -55,47 +57,72 @@ struct WgArgs {
     int H, W, cin, cout, ups, tm, tn, nparts;
 };
 
+// NCO = 16-filter tiles per wave: the nine activation loads of a 4-pixel group feed 9 x NCO MFMAs (the first version of this kernel
+// gave a wave ONE filter tile -- ten scalar loads per nine MFMAs -- and ran three 64-bit divisions per group: 61 % of the 128 x 128
+// variant's training step at 8 % of the matrix peak).  A part is a range of whole conv rows, so the inner loop has no division.
+template <int NCO>
 __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int tiles = g.tm * g.tn, wg_per_part = (tiles + 3) / 4;
-    const int p = blockIdx.x / wg_per_part, tile = (blockIdx.x % wg_per_part) * 4 + wave;
-    if (tile >= tiles) return;
-    const int cib = tile / g.tn, cob = tile % g.tn;
-    const int ci = cib * 16 + li, co = cob * 16 + li;
+    const int tng = (g.tn + NCO - 1) / NCO;                 // filter-tile groups
+    const int units = g.tm * tng, wg_per_part = (units + 3) / 4;
+    const int p = blockIdx.x / wg_per_part, unit = (blockIdx.x % wg_per_part) * 4 + wave;
+    if (unit >= units) return;
+    const int cib = unit / tng, cog = unit % tng;
+    const int ci = cib * 16 + li;
     const int H = g.H, W = g.W, Ws = g.ups ? W / 2 : W, Hs = g.ups ? H / 2 : H;
-    const long groups = g.n * H * (W / 4);                 // groups of 4 consecutive pixels of a row
-    const long g0 = (groups * p) / g.nparts, g1 = (groups * (p + 1)) / g.nparts;
-    f32x4 acc[9];
+    const long rows = g.n * H;
+    const long r0 = (rows * p) / g.nparts, r1 = (rows * (p + 1)) / g.nparts;
+    int co[NCO];
+    bool cok[NCO];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (long q = g0; q < g1; ++q) {
-        const int x = (int)(q % (W / 4)) * 4 + kq;
-        const long row = q / (W / 4);
-        const int y = (int)(row % H);
+    for (int j = 0; j < NCO; ++j) { co[j] = (cog * NCO + j) * 16 + li; cok[j] = co[j] < g.cout; }
+    const bool ciok = ci < g.cin;
+    f32x4 acc[NCO][9];
+#pragma unroll
+    for (int j = 0; j < NCO; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[j][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (long row = r0; row < r1; ++row) {
         const long cell = row / H;
-        const float b = co < g.cout ? g.dz[((cell * H + y) * W + x) * g.cout + co] : 0.0f;
+        const int y = (int)(row - cell * H);
+        const float* dzr = g.dz + ((cell * H + y) * W) * g.cout;
+        // the three activation rows of this conv row (null outside the image)
+        const float* xr[3];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            float a = 0.0f;
-            if (ci < g.cin && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const int sy = g.ups ? yy >> 1 : yy, sx = g.ups ? xx >> 1 : xx;
-                a = g.xin[((cell * Hs + sy) * Ws + sx) * g.cin + ci];
+        for (int d = 0; d < 3; ++d) {
+            const int yy = y + d - 1;
+            xr[d] = (yy >= 0 && yy < H && ciok) ? g.xin + ((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws) * g.cin + ci : nullptr;
+        }
+        for (int x = kq; x < W; x += 4) {
+            float b[NCO];
+#pragma unroll
+            for (int j = 0; j < NCO; ++j) b[j] = cok[j] ? dzr[(size_t)x * g.cout + co[j]] : 0.0f;
+            float a[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int xx = x + t % 3 - 1;
+                const float* r = xr[t / 3];
+                a[t] = (r && xx >= 0 && xx < W) ? r[(size_t)(g.ups ? xx >> 1 : xx) * g.cin] : 0.0f;
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < NCO; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[j], acc[j][t], 0, 0, 0);
         }
     }
     // D: lane = filter li of the tile, registers = input channels 4 kq .. 4 kq + 3
-    if (co < g.cout) {
-        float* o = g.part + (size_t)p * 9 * g.cin * g.cout;
+    float* o = g.part + (size_t)p * 9 * g.cin * g.cout;
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+        if (!cok[j]) continue;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c2 = cib * 16 + 4 * kq + r;
-                if (c2 < g.cin) o[((size_t)t * g.cin + c2) * g.cout + co] = acc[t][r];
+                if (c2 < g.cin) o[((size_t)t * g.cin + c2) * g.cout + co[j]] = acc[j][t][r];
             }
     }
 }
@@ -118,21 +145,34 @@ hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int 
     return hipGetLastError();
 }
 
+// filter tiles per wave and workgroups per part for a layer (shared by the launcher and the partial-sum buffer sizing)
+static void wgrad_generic_shape(int cin, int cout, int* nco, int* wg_per_part)
+{
+    const int tm = (cin + 15) / 16, tn = (cout + 15) / 16;
+    static const int cap = getenv("CS_WGRAD_NCO") ? atoi(getenv("CS_WGRAD_NCO")) : 4;     // A/B knob
+    *nco = (tn >= 4 && cap >= 4) ? 4 : ((tn >= 2 && cap >= 2) ? 2 : 1);
+    *wg_per_part = (tm * ((tn + *nco - 1) / *nco) + 3) / 4;
+}
+
 hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, int64_t n, int H, int W, int cin, int cout, int ups,
                                 int max_parts, int* nparts, hipStream_t s)
 {
     WgArgs g;
     g.xin = xin; g.dz = dz; g.part = part; g.n = n; g.H = H; g.W = W; g.cin = cin; g.cout = cout; g.ups = ups;
     g.tm = (cin + 15) / 16; g.tn = (cout + 15) / 16;
-    const int wg_per_part = (g.tm * g.tn + 3) / 4;
-    const long groups = (long)n * H * (W / 4);
+    int nco, wg_per_part;
+    wgrad_generic_shape(cin, cout, &nco, &wg_per_part);
+    const long rows = (long)n * H;
     long np = 2048 / wg_per_part;
     if (np > max_parts) np = max_parts;
-    if (np > groups) np = groups;
+    if (np > rows) np = rows;
     if (np < 1) np = 1;
     g.nparts = (int)np;
     *nparts = g.nparts;
-    hipLaunchKernelGGL(wgrad_generic_kernel, dim3((unsigned)(g.nparts * wg_per_part)), dim3(256), 0, s, g);
+    const dim3 grid((unsigned)(g.nparts * wg_per_part));
+    if (nco == 4) hipLaunchKernelGGL(wgrad_generic_kernel<4>, grid, dim3(256), 0, s, g);
+    else if (nco == 2) hipLaunchKernelGGL(wgrad_generic_kernel<2>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(wgrad_generic_kernel<1>, grid, dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
@@ -141,7 +181,8 @@ hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, 
 // ------------------------------------------------------------------------------------------------ orchestration
 static int gen_parts(const cs_trainer* t, int l)
 {
-    const int wg_per_part = (((t->cin(l) + 15) / 16) * ((t->ch[l] + 15) / 16) + 3) / 4;
+    int nco, wg_per_part;
+    cs::wgrad_generic_shape(t->cin(l), t->ch[l], &nco, &wg_per_part);
     long np = 2048 / wg_per_part;
     if (np > TRAIN_MAX_PARTS) np = TRAIN_MAX_PARTS;
     return np < 1 ? 1 : (int)np;
