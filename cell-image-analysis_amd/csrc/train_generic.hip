@@ -57,28 +57,39 @@ struct WgArgs {
     int H, W, cin, cout, ups, tm, tn, nparts;
 };
 
-// NCO = 16-filter tiles per wave: the nine activation loads of a 4-pixel group feed 9 x NCO MFMAs (the first version of this kernel
-// gave a wave ONE filter tile -- ten scalar loads per nine MFMAs -- and ran three 64-bit divisions per group: 61 % of the 128 x 128
-// variant's training step at 8 % of the matrix peak).  A part is a range of whole conv rows, so the inner loop has no division.
+// NCO = 16-filter tiles per wave.  A workgroup (4 waves = 4 (input-channel tile, filter-tile group) units of ONE part) walks the
+// part's conv rows; per row it stages the three activation rows in conv-grid coordinates (halo and UpSampling2D resolved while
+// staging: 16-byte global loads along the channels) and the dz row in LDS, then every wave runs W / 4 pixel groups x 9 taps x NCO
+// MFMAs from LDS (lane = (channel, pixel): 4-byte reads, 16 consecutive channels per pixel; the pixel stride is padded to
+// 16 (mod 32) floats so the two pixels of a half wave fall on different banks).
+// History: the first version gave a wave one filter tile, loaded every operand with scalar global loads and ran three 64-bit
+// divisions per 4-pixel group -- 61 % of the 128 x 128 variant's training step at 8 % of the matrix peak; walking whole rows took
+// the step from 4.68 to 3.26 ms, the LDS staging below to 2.8 ms.
+__device__ __forceinline__ int wg_pad(int c) { return c + ((48 - (c & 31)) & 31); }      // smallest c' >= c with c' = 16 (mod 32)
+
 template <int NCO>
 __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int tng = (g.tn + NCO - 1) / NCO;                 // filter-tile groups
     const int units = g.tm * tng, wg_per_part = (units + 3) / 4;
     const int p = blockIdx.x / wg_per_part, unit = (blockIdx.x % wg_per_part) * 4 + wave;
-    if (unit >= units) return;
-    const int cib = unit / tng, cog = unit % tng;
+    const bool active = unit < units;                       // idle waves still stage and take the barriers
+    const int cib = active ? unit / tng : 0, cog = active ? unit % tng : 0;
     const int ci = cib * 16 + li;
-    const int H = g.H, W = g.W, Ws = g.ups ? W / 2 : W, Hs = g.ups ? H / 2 : H;
+    const int H = g.H, W = g.W, cin = g.cin, cout = g.cout, Ws = g.ups ? W / 2 : W, Hs = g.ups ? H / 2 : H;
+    const int xs_ = wg_pad(cin), zs_ = wg_pad(cout);        // staged pixel strides (floats)
+    float* const Xs = wsm;                                  // [3][W + 2][xs_]
+    float* const Zs = wsm + 3 * (W + 2) * xs_;              // [W][zs_]
     const long rows = g.n * H;
     const long r0 = (rows * p) / g.nparts, r1 = (rows * (p + 1)) / g.nparts;
     int co[NCO];
     bool cok[NCO];
 #pragma unroll
-    for (int j = 0; j < NCO; ++j) { co[j] = (cog * NCO + j) * 16 + li; cok[j] = co[j] < g.cout; }
-    const bool ciok = ci < g.cin;
+    for (int j = 0; j < NCO; ++j) { co[j] = (cog * NCO + j) * 16 + li; cok[j] = active && co[j] < cout; }
+    const bool ciok = active && ci < cin;
     f32x4 acc[NCO][9];
 #pragma unroll
     for (int j = 0; j < NCO; ++j)
@@ -87,33 +98,63 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
     for (long row = r0; row < r1; ++row) {
         const long cell = row / H;
         const int y = (int)(row - cell * H);
-        const float* dzr = g.dz + ((cell * H + y) * W) * g.cout;
-        // the three activation rows of this conv row (null outside the image)
-        const float* xr[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int yy = y + d - 1;
-            xr[d] = (yy >= 0 && yy < H && ciok) ? g.xin + ((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws) * g.cin + ci : nullptr;
-        }
-        for (int x = kq; x < W; x += 4) {
-            float b[NCO];
-#pragma unroll
-            for (int j = 0; j < NCO; ++j) b[j] = cok[j] ? dzr[(size_t)x * g.cout + co[j]] : 0.0f;
-            float a[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int xx = x + t % 3 - 1;
-                const float* r = xr[t / 3];
-                a[t] = (r && xx >= 0 && xx < W) ? r[(size_t)(g.ups ? xx >> 1 : xx) * g.cin] : 0.0f;
+        __syncthreads();                                    // the previous row's MFMAs are done with the staged rows
+        // activation rows y - 1 .. y + 1 at conv-grid columns -1 .. W
+        if ((cin & 3) == 0) {
+            const int c4n = cin >> 2, per_row = (W + 2) * c4n;
+            for (int e = tid; e < 3 * per_row; e += 256) {
+                const int d = e / per_row, rem = e - d * per_row, xx = rem / c4n - 1, c4 = rem - (xx + 1) * c4n;
+                const int yy = y + d - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                    v = *(const f32x4*)(g.xin + ((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws + (g.ups ? xx >> 1 : xx)) * cin + 4 * c4);
+                *(f32x4*)(Xs + (d * (W + 2) + xx + 1) * xs_ + 4 * c4) = v;
             }
+        } else {
+            const int per_row = (W + 2) * cin;
+            for (int e = tid; e < 3 * per_row; e += 256) {
+                const int d = e / per_row, rem = e - d * per_row, xx = rem / cin - 1, c = rem - (xx + 1) * cin;
+                const int yy = y + d - 1;
+                float v = 0.0f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = g.xin[((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws + (g.ups ? xx >> 1 : xx)) * cin + c];
+                Xs[(d * (W + 2) + xx + 1) * xs_ + c] = v;
+            }
+        }
+        const float* dzr = g.dz + ((cell * H + y) * W) * cout;
+        if ((cout & 3) == 0) {
+            const int c4n = cout >> 2;
+            for (int e = tid; e < W * c4n; e += 256) {
+                const int x = e / c4n, c4 = e - x * c4n;
+                *(f32x4*)(Zs + x * zs_ + 4 * c4) = *(const f32x4*)(dzr + (size_t)x * cout + 4 * c4);
+            }
+        } else {
+            for (int e = tid; e < W * cout; e += 256) {
+                const int x = e / cout, c = e - x * cout;
+                Zs[x * zs_ + c] = dzr[e];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const float* xa = Xs + kq * xs_ + (ciok ? ci : 0);       // tap (d, dx) of pixel x: row d, staged column x + dx
+            const float* zb = Zs + kq * zs_;
+            for (int x0 = 0; x0 < W; x0 += 4) {
+                float b[NCO], a[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                for (int j = 0; j < NCO; ++j) b[j] = cok[j] ? zb[x0 * zs_ + co[j]] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < NCO; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[j], acc[j][t], 0, 0, 0);
+                for (int t = 0; t < 9; ++t) {
+                    const float v = xa[((t / 3) * (W + 2) + x0 + t % 3) * xs_];
+                    a[t] = ciok ? v : 0.0f;
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < NCO; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[j], acc[j][t], 0, 0, 0);
+            }
         }
     }
     // D: lane = filter li of the tile, registers = input channels 4 kq .. 4 kq + 3
-    float* o = g.part + (size_t)p * 9 * g.cin * g.cout;
+    float* o = g.part + (size_t)p * 9 * cin * cout;
 #pragma unroll
     for (int j = 0; j < NCO; ++j) {
         if (!cok[j]) continue;
@@ -122,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c2 = cib * 16 + 4 * kq + r;
-                if (c2 < g.cin) o[((size_t)t * g.cin + c2) * g.cout + co[j]] = acc[j][t][r];
+                if (c2 < cin) o[((size_t)t * cin + c2) * cout + co[j]] = acc[j][t][r];
             }
     }
 }
@@ -149,8 +190,8 @@ hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int 
 static void wgrad_generic_shape(int cin, int cout, int* nco, int* wg_per_part)
 {
     const int tm = (cin + 15) / 16, tn = (cout + 15) / 16;
-    static const int cap = getenv("CS_WGRAD_NCO") ? atoi(getenv("CS_WGRAD_NCO")) : 4;     // A/B knob
-    *nco = (tn >= 4 && cap >= 4) ? 4 : ((tn >= 2 && cap >= 2) ? 2 : 1);
+    // two filter tiles per wave: 160 VGPRs (three waves per SIMD); four (300 VGPRs, one wave per SIMD) measured 3 % slower, one equal
+    *nco = tn >= 2 ? 2 : 1;
     *wg_per_part = (tm * ((tn + *nco - 1) / *nco) + 3) / 4;
 }
 
@@ -170,9 +211,20 @@ hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, 
     g.nparts = (int)np;
     *nparts = g.nparts;
     const dim3 grid((unsigned)(g.nparts * wg_per_part));
-    if (nco == 4) hipLaunchKernelGGL(wgrad_generic_kernel<4>, grid, dim3(256), 0, s, g);
-    else if (nco == 2) hipLaunchKernelGGL(wgrad_generic_kernel<2>, grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(wgrad_generic_kernel<1>, grid, dim3(256), 0, s, g);
+    auto pad = [](int c) { return c + ((48 - (c & 31)) & 31); };
+    const size_t lds = ((size_t)3 * (W + 2) * pad(cin) + (size_t)W * pad(cout)) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e;
+#define WG_GO(N)                                                                                                                   \
+    do {                                                                                                                           \
+        e = hipFuncSetAttribute((const void*)wgrad_generic_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        if (e == hipSuccess) hipLaunchKernelGGL(wgrad_generic_kernel<N>, grid, dim3(256), lds, s, g);                              \
+    } while (0)
+    if (nco == 4) WG_GO(4);
+    else if (nco == 2) WG_GO(2);
+    else WG_GO(1);
+#undef WG_GO
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
