@@ -126,6 +126,7 @@ size_t pack_generic_folded(int cin, int cout, const float* hwio, float* dst);
 // folded-upsample form, fed pack_generic_folded's kernels with ntaps = 16; otherwise the HWIO kernel with ntaps = 9)
 int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups);
 size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_t* dst);     // returns the number of bf16 values
+hipError_t launch_pack_generic_bf16x3(const float* w, int ntaps, int cin, int cout, uint16_t* dst, hipStream_t stream);   // the same on the device
 hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
                                   int cout, int ups, int epi, hipStream_t stream);
 // the 1-filter sigmoid conv behind an UpSampling2D as a cin -> 16 GEMM on bf16 MFMAs + a gather (cin 32 or 64):

@@ -325,6 +325,28 @@ __global__ __launch_bounds__(512) void conv_last_x3_kernel(const float* __restri
     }
 }
 
+// pack_generic_bf16x3 on the device (training: the weights change every step).  One thread per (tap, block, filter, channel).
+__global__ void pack_generic_bf16x3_kernel(const float* __restrict__ w, int ntaps, int cin, int cout, uint16_t* __restrict__ dst)
+{
+    const int coutp = (cout + 15) & ~15, nkb = cin / 32;
+    const long total = (long)ntaps * nkb * coutp * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 31);
+        const int co = (int)((i >> 5) % coutp);
+        const long tk = (i >> 5) / coutp;                       // tap * nkb + block
+        const int kb = (int)(tk % nkb), t = (int)(tk / nkb);
+        const float v = co < cout ? w[((size_t)t * cin + 32 * kb + k) * cout + co] : 0.0f;
+        const __bf16 a1 = (__bf16)v;
+        const float r1 = v - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        const __bf16 a3 = (__bf16)(r1 - (float)a2);
+        const size_t base = ((size_t)tk * 3 * coutp + co) * 32 + k;
+        dst[base] = __builtin_bit_cast(uint16_t, a1);
+        dst[base + (size_t)coutp * 32] = __builtin_bit_cast(uint16_t, a2);
+        dst[base + (size_t)2 * coutp * 32] = __builtin_bit_cast(uint16_t, a3);
+    }
+}
+
 uint16_t bf16_rne(float x)
 {
     uint32_t u;
@@ -528,6 +550,16 @@ hipError_t launch_conv_last_x3(const float* in, const uint16_t* wplanes, const f
         if ((e = hipFuncSetAttribute((const void*)conv_last_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(conv_last_x3_kernel<64>, dim3(grid), dim3(512), lds, stream, in, (const bf16x8*)wplanes, ep, out, (long)n, H, W, SRS, NT, P);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_generic_bf16x3(const float* w, int ntaps, int cin, int cout, uint16_t* dst, hipStream_t stream)
+{
+    const long total = (long)ntaps * (cin / 32) * ((cout + 15) & ~15) * 32;
+    if (total <= 0) return hipSuccess;
+    long grid = (total + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(pack_generic_bf16x3_kernel, dim3((unsigned)grid), dim3(256), 0, stream, w, ntaps, cin, cout, dst);
     return hipGetLastError();
 }
 

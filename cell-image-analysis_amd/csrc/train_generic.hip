@@ -259,6 +259,15 @@ int gen_train_setup(cs_trainer* t)
         if ((rc = t->wpart[l].ensure((size_t)gen_parts(t, l) * 9 * t->cin(l) * t->ch[l] * 4))) return rc;
     }
     if ((rc = t->descs.ensure(2 * TR_MAXL * sizeof(ReduceDesc))) || (rc = t->scal.ensure(16))) return rc;
+    // convs that run on bf16 MFMAs (conv_generic_x3.hip: the shape has a plan, cin 32 / 64 / 128, not upsample-fed): forward with
+    // the kernel as it is, backward-data with the flipped kernel (channel roles swapped, never upsample-fed: the 2x2 sum follows)
+    for (int l = 0; l < t->n_conv; ++l) {
+        const int cin = t->cin(l), C = t->ch[l];
+        t->x3f[l] = l < t->n_conv - 1 && l <= t->n_enc && conv_generic_x3_takes(t->gh[l], t->gw[l], cin, C, 0);
+        t->x3t[l] = l > 0 && conv_generic_x3_takes(t->gh[l], t->gw[l], C, cin, 0);
+        if (t->x3f[l] && (rc = t->wx3f[l].ensure(pack_generic_bf16x3(9, cin, C, nullptr, nullptr) * 2))) return rc;
+        if (t->x3t[l] && (rc = t->wx3t[l].ensure(pack_generic_bf16x3(9, C, cin, nullptr, nullptr) * 2))) return rc;
+    }
     return gen_train_repack(t);
 }
 
@@ -267,6 +276,10 @@ int gen_train_repack(cs_trainer* t)
     float* P = t->P.as<float>();
     for (int l = 1; l < t->n_conv; ++l)
         LCHK(launch_flip_transpose(P + t->off_k[l], t->cin(l), t->ch[l], t->wft[l].as<float>(), t->stream));
+    for (int l = 0; l < t->n_conv; ++l) {
+        if (t->x3f[l]) LCHK(launch_pack_generic_bf16x3(P + t->off_k[l], 9, t->cin(l), t->ch[l], t->wx3f[l].as<uint16_t>(), t->stream));
+        if (t->x3t[l]) LCHK(launch_pack_generic_bf16x3(t->wft[l].as<float>(), 9, t->ch[l], t->cin(l), t->wx3t[l].as<uint16_t>(), t->stream));
+    }
     return CS_OK;
 }
 
@@ -316,8 +329,12 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
     for (int l = 0; l < last; ++l) {
         const int C = t->ch[l], pool = l < t->n_enc;
         const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
-        LCHK(launch_conv_generic(in, P + t->off_k[l], P + t->off_b[l], t->r[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C,
-                                 l > t->n_enc, GEN_EPI_RELU, s));
+        if (t->x3f[l])
+            LCHK(launch_conv_generic_x3(in, t->wx3f[l].as<uint16_t>(), P + t->off_b[l], t->r[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C,
+                                        0, GEN_EPI_RELU, s));
+        else
+            LCHK(launch_conv_generic(in, P + t->off_k[l], P + t->off_b[l], t->r[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C,
+                                     l > t->n_enc, GEN_EPI_RELU, s));
         int G1 = 0;
         LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * t->gh[l] * t->gw[l], C, t->part_stats.as<float>(), &G1, s));
         LCHK(launch_bn_stats_final(t->part_stats.as<float>(), G1, C, t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l],
@@ -348,8 +365,12 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
                                   &t->np_w[l], s));
         if (l > 0) {   // dL/d(input of conv l): conv of dz with the flipped kernel, channel roles swapped
             float* dst = ups ? t->dup.as<float>() : t->da[l - 1].as<float>();
-            LCHK(launch_conv_generic(t->dz[l].as<float>(), t->wft[l].as<float>(), nullptr, dst, B, t->gh[l], t->gw[l], C, t->cin(l), 0,
-                                     GEN_EPI_PLAIN, s));
+            if (t->x3t[l])
+                LCHK(launch_conv_generic_x3(t->dz[l].as<float>(), t->wx3t[l].as<uint16_t>(), nullptr, dst, B, t->gh[l], t->gw[l], C, t->cin(l), 0,
+                                            GEN_EPI_PLAIN, s));
+            else
+                LCHK(launch_conv_generic(t->dz[l].as<float>(), t->wft[l].as<float>(), nullptr, dst, B, t->gh[l], t->gw[l], C, t->cin(l), 0,
+                                         GEN_EPI_PLAIN, s));
             if (ups) LCHK(launch_sumpool2x2(t->dup.as<float>(), t->da[l - 1].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), s));
         }
     }

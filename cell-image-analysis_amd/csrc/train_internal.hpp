@@ -26,6 +26,9 @@ struct cs_trainer {
     long step = 0;
     // packed operands, rebuilt after every update (reference graph: MFMA fragments; generic: flipped/transposed HWIO kernels)
     cs::DevBuf wf[TR_MAXL], wft[TR_MAXL], w7eff, ep_inf[TR_MAXL];
+    // generic trainer: split-bf16 planes of the forward kernels / of the flipped kernels (conv_generic_x3.hip), re-packed with the weights
+    cs::DevBuf wx3f[TR_MAXL], wx3t[TR_MAXL];
+    bool x3f[TR_MAXL] = {false}, x3t[TR_MAXL] = {false};
     // batch tensors
     cs::DevBuf x, y, r[TR_MAXL], a[TR_MAXL], out, errpart, dz[TR_MAXL], da[TR_MAXL], stats[TR_MAXL], dup;
     cs::DevBuf aug_tf, aug_in, aug_out;
