@@ -13,12 +13,14 @@ N = 1 runs BASELINE.json configs[2] (1M crops on one GPU); N > 1 shards N x 1M c
 contiguous index ranges (weak scaling, no data-path collective before the final gather).
 
 Rank 0 prints ONE JSON line; besides the contract keys it carries
-  roofline      the dominant kernel priced against the exact-fp32 MFMA peak.  `achieved` / `frac`
-                count the matrix-pipe work the kernel EXECUTES (its own MFMA count x 2,048 FLOP, the
-                number SQ_INSTS_MFMA reports) over its launch time from HIP events recorded on the
-                library's stream inside the timed steps -- never above 1; the reference graph's
-                algorithmic FLOPs of the same layers are carried as `achieved_algorithmic` /
-                `algorithmic_speedup` (Winograd and the folded upsample execute fewer multiply-adds).
+  roofline      the dominant kernel priced against the matrix pipes it runs on.  `achieved` counts the matrix-pipe work
+                the kernel EXECUTES (its fp32 MFMAs x 2,048 FLOP + its bf16 MFMAs x 16,384 FLOP -- the library reports
+                both counts, their sum is what SQ_INSTS_MFMA shows) over its launch time from HIP events recorded on
+                the library's stream inside the timed steps; `peak` is the rate that same instruction mix reaches with
+                both pipes at their peaks (157.3 TFLOP/s for a pure fp32-MFMA kernel, 2,500 for a pure bf16 one), so
+                `frac` = achieved / peak is the fraction of the kernel's time its matrix work needs at peak -- never
+                above 1; the reference graph's algorithmic FLOPs of the same layers are `achieved_algorithmic`
+                (Winograd and the folded upsample execute fewer multiply-adds).
                 `traffic` = HBM bytes per launch from two rocprofv3 PMC passes (FETCH_SIZE x 2 on
                 gfx950, WRITE_SIZE) of THIS tree: collected by this run in two child processes before
                 the parent touches the GPU, or taken from profiles/*_pmc_traffic.json only when that
