@@ -186,6 +186,10 @@ hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int 
     return hipGetLastError();
 }
 
+// Layers with a small kernel (the first and the last conv: 9 x 1 x 32 and 9 x 32 x 1 weights) have one or two (channel tile, filter
+// tile) units, i.e. one or two busy waves per part: they get four times the parts (their partial sums are 1 KB each)
+static int wgrad_generic_part_cap(int cin, int cout, int max_parts) { return 9L * cin * cout <= 16384 ? 4 * max_parts : max_parts; }
+
 // filter tiles per wave and workgroups per part for a layer (shared by the launcher and the partial-sum buffer sizing)
 static void wgrad_generic_shape(int cin, int cout, int* nco, int* wg_per_part)
 {
@@ -205,6 +209,7 @@ hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, 
     wgrad_generic_shape(cin, cout, &nco, &wg_per_part);
     const long rows = (long)n * H;
     long np = 2048 / wg_per_part;
+    max_parts = wgrad_generic_part_cap(cin, cout, max_parts);
     if (np > max_parts) np = max_parts;
     if (np > rows) np = rows;
     if (np < 1) np = 1;
@@ -236,7 +241,8 @@ static int gen_parts(const cs_trainer* t, int l)
     int nco, wg_per_part;
     cs::wgrad_generic_shape(t->cin(l), t->ch[l], &nco, &wg_per_part);
     long np = 2048 / wg_per_part;
-    if (np > TRAIN_MAX_PARTS) np = TRAIN_MAX_PARTS;
+    const int cap = cs::wgrad_generic_part_cap(t->cin(l), t->ch[l], TRAIN_MAX_PARTS);
+    if (np > cap) np = cap;
     return np < 1 ? 1 : (int)np;
 }
 
