@@ -9,8 +9,8 @@ A "step" is one pass of the hot path -- compute_anomaly_scores, improved_detecti
 CAE forward + per-cell MSE/MAE + encoder features + RobustScaler + PCA + 2x one-class-SVM
 score -- over this rank's batch of synthetic 64x64 crops that are already resident in HBM,
 ending with the per-cell results on the host of rank 0 (for N > 1: after the RCCL gather).
-N = 1 runs BASELINE.json configs[2] (1M crops on one GPU); N > 1 shards N x 1M crops by
-contiguous index ranges (weak scaling, no data-path collective before the final gather).
+N = 1 runs BASELINE.json configs[2] (1M crops on one GPU); N > 1 runs configs[3]'s layout at its per-GPU size: 1.25 M crops
+per GPU (10 M global at N = 8), contiguous index ranges, no data-path collective before the final RCCL gather (weak scaling).
 
 Rank 0 prints ONE JSON line; besides the contract keys it carries
   roofline      the dominant kernel priced against the matrix pipes it runs on.  `achieved` counts the matrix-pipe work
@@ -30,7 +30,14 @@ Rank 0 prints ONE JSON line; besides the contract keys it carries
                 predict batch of 32, autoencoder pass + separate encoder pass, NumPy MSE/MAE, the real
                 scikit-learn transform / predict / decision_function calls (4 SVM passes) -- on
                 configs[0]'s 128 crops and on 4,096; plus the OpenMP oracle port (rank 0, N = 1 only)
-  train_leg     a short driver-timed run of BASELINE.json configs[1] (CAE training, batch 32)
+  exact_fp32    the same step with every contraction on the fp32 matrix instructions (a second engine under CS_NO_BF16X3=1):
+                the headline runs the fp32 contractions as split 16-bit products (dtype says so), this is the bit-for-bit
+                fp32-MFMA form next to it
+  e2e_raw       the production path end to end: 1 M RAW uint16 bounding-box crops (sides U[32,100]) in pinned host memory ->
+                H2D -> cs_preprocess (CLAHE + anti-aliased resize, improved_detection.py:98-99) -> cs_screen -> 18 B/cell on the
+                host, the copy of chunk i + 1 under the kernels of chunk i
+  train_leg     BASELINE.json configs[1] as written: 50,000 synthetic crops -> 40,000 / 10,000, one epoch = 1,250 augmented
+                batch-32 steps + the validation pass
   small_n       single-call latency of the hot path from host buffers at N = 128 / 1,024 / 10,240
 """
 import argparse
@@ -65,14 +72,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=1_000_000, help="crops per GPU per step")
+    ap.add_argument("--cells", type=int, default=0, help="crops per GPU per step (0 = BASELINE.json: 1,000,000 at N = 1 [configs[2]], "
+                                                         "1,250,000 at N > 1 [configs[3]: 10 M over 8 GPUs])")
     ap.add_argument("--chunk", type=int, default=65536, help="cells per internal pass (workspace ~0.3 MB per cell)")
     ap.add_argument("--train-cells", type=int, default=5000, help="synthetic crops the detector is fit on")
     ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU port baseline (0 = auto, ~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic with rocprofv3 child passes")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the training leg and the small-N latency leg")
-    ap.add_argument("--train-steps", type=int, default=200)
+    ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = one configs[1] epoch: 1,250)")
+    ap.add_argument("--raw-crops", type=int, default=1_000_000, help="raw crops of the e2e_raw leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
@@ -274,34 +283,149 @@ def _cpu_model():
 
 # ------------------------------------------------------------------------------------------- extra legs
 def train_leg(steps, local_rank, seed):
-    """BASELINE.json configs[1]: CAE training, batch 32, crops resident in HBM; `steps` timed fit() batches."""
+    """BASELINE.json configs[1] as written (CAE_improved_modeltrain.py:240,246-254,286-293): 50,000 synthetic crops split
+    40,000 / 10,000, resident in HBM; one epoch = 1,250 fit() batches of 32 -- shuffled gather, the reference's
+    ImageDataGenerator augmentation on the INPUT only (cs_train_augment on the device), forward + backward + Adam -- then the
+    validation pass over the 10,000 held-out crops.  Nothing synchronises the host inside the epoch: the per-step loss / MAE
+    stay on the device and are read once at the end (cs_train_read_metrics)."""
+    import numpy as np
     import torch
     from cellscreen import synth
+    from cellscreen.augment import ImageDataGenerator
     from cellscreen.trainer import Trainer
     dev = torch.device("cuda", local_rank)
-    X = torch.from_numpy(synth.blob_crops(seed, 4096)).to(dev)
+    n_all, n_val = 50_000, 10_000
+    X = torch.from_numpy(synth.blob_crops(seed, n_all)).to(dev)
+    Xtr, Xva = X[:n_all - n_val], X[n_all - n_val:]
+    full_epoch = steps <= 0
+    steps = (n_all - n_val) // 32 if full_epoch else steps
     tr = Trainer(synth.random_cae(seed=seed, trivial_bn=True), device_id=local_rank)
-    gen = torch.Generator(device=dev); gen.manual_seed(1234)
-    idx = torch.randint(0, len(X), (steps + 20, 32), device=dev, generator=gen)
-    first = last = None
+    gen = ImageDataGenerator(rotation_range=2, width_shift_range=0.02, height_shift_range=0.02, zoom_range=0.02,
+                             horizontal_flip=True, vertical_flip=True, fill_mode="nearest")        # CAE...:246-254
+    rng = np.random.default_rng(1234)
+    warm = 20
+    tg = torch.Generator(device=dev); tg.manual_seed(1234)
     try:
-        for i in range(20):
-            xb = X[idx[i]].contiguous()                # the wrapper orders the library's stream after torch's
-            l, _ = tr.step(xb, xb, 1e-3)
+        idx = torch.randint(0, len(Xtr), (warm, 32), device=dev, generator=tg)
+        first = None
+        for i in range(warm):
+            yb = Xtr[idx[i]].contiguous()
+            l, _ = tr.step(tr.augment(yb, gen.random_transforms(32, (64, 64), rng)), yb, 1e-3)
             first = l if first is None else first
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(20, steps + 20):
-            xb = X[idx[i]].contiguous()
-            last, _ = tr.step(xb, xb, 1e-3)
+        perm = torch.randperm(len(Xtr), device=dev, generator=tg)[:steps * 32].view(steps, 32)       # one shuffled pass
+        tr.reset_metrics()
+        for i in range(steps):
+            yb = Xtr[perm[i]].contiguous()                 # the wrapper orders the library's stream after torch's
+            tr.step_async(tr.augment(yb, gen.random_transforms(32, (64, 64), rng)), yb, 1e-3)
+        loss_epoch, mae_epoch, _ = tr.read_metrics()       # one host round trip for the epoch (Keras's running means)
+        torch.cuda.synchronize()
+        t_train = time.perf_counter() - t0
+        val_loss, val_mae = tr.evaluate(Xva, Xva) if full_epoch else (None, None)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     finally:
         tr.close()
-    return dict(workload="BASELINE.json configs[1]: CAE training (fwd + bwd + Adam, BN batch statistics), batch 32, fp32, 1 GPU",
-                steps=steps, ms_per_step=round(el / steps * 1e3, 4), cells_per_s=round(steps * 32 / el, 1),
-                tflops_algorithmic=round(steps * 32 / el * 3 * FLOP_PER_CELL / 1e12, 3),
-                epoch_seconds_at_1250_steps=round(el / steps * 1250, 3), loss_first_last=[round(first, 6), round(last, 6)])
+    return dict(workload="BASELINE.json configs[1]: CAE training (fwd + bwd + Adam, BN batch statistics, on-device augmentation of the input), "
+                         "50,000 synthetic crops -> 40,000 / 10,000, batch 32, fp32, 1 GPU" + ("" if full_epoch else " (--train-steps: partial epoch, no validation pass)"),
+                steps=steps, ms_per_step=round(t_train / steps * 1e3, 4), cells_per_s=round(steps * 32 / t_train, 1),
+                tflops_algorithmic=round(steps * 32 / t_train * 3 * FLOP_PER_CELL / 1e12, 3),
+                epoch_s=round(el, 3) if full_epoch else None, validation_s=round(el - t_train, 3) if full_epoch else None,
+                loss_first_step=round(first, 6), loss_epoch_mean=round(loss_epoch, 6), mae_epoch_mean=round(mae_epoch, 6),
+                val_loss=None if val_loss is None else round(val_loss, 6))
+
+
+def exact_fp32_leg(weights, det, x, out, args, local_rank):
+    """The same step on the fp32 matrix instructions throughout (CS_NO_BF16X3=1 selects the fp32-MFMA kernels at model creation)."""
+    import torch
+    from cellscreen.engine import Engine
+    os.environ["CS_NO_BF16X3"] = "1"
+    try:
+        e = Engine.from_weights(weights, None, det, device_id=local_rank)
+    finally:
+        del os.environ["CS_NO_BF16X3"]
+    try:
+        e.set_chunk(args.chunk)
+        e.screen(x, out=out, out_device=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e.screen(x, out=out, out_device=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+    finally:
+        e.close()
+    return dict(value=round(len(x) / dt, 1), unit="cells/s", ms_per_step=round(dt * 1e3, 3), steps=3, dtype="f32 (v_mfma_f32_16x16x4_f32 for every contraction)",
+                note="results stay on the device in this leg (no 18 B/cell copy)")
+
+
+def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
+    """improved_detection.py:98-99 -> :199 as one pipeline: raw uint16 bounding-box crops (ragged, sides U[32,100]) in PINNED host
+    memory -> H2D (copy stream, chunk i + 1 under the kernels of chunk i) -> cs_preprocess (device -> device) -> cs_screen
+    -> 18 B/cell back on the host."""
+    import numpy as np
+    import torch
+    from cellscreen import preprocess as pp
+    from cellscreen import synth
+    dev = torch.device("cuda", local_rank)
+    base = synth.raw_crops(seed, 4096, np.uint16, 32, 100)
+    bpix, boff, bhs, bws = pp.pack_crops(base)
+    reps = (n + len(base) - 1) // len(base)
+    hs, ws = np.tile(bhs, reps)[:n], np.tile(bws, reps)[:n]
+    sizes = hs.astype(np.int64) * ws.astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    total = int(sizes.sum())
+    host = torch.empty(total, dtype=torch.int16, pin_memory=True)          # uint16 pixels (torch has no pinned uint16 before 2.3-style views)
+    hv = host.numpy().view(np.uint16)
+    for r in range(reps):                                                  # the packed base, repeated
+        lo = r * len(bpix)
+        m = min(len(bpix), total - lo)
+        if m > 0:
+            hv[lo:lo + m] = bpix[:m]
+    proc = pp.Preprocessor(local_rank)
+    copy_stream = torch.cuda.Stream(device=dev)
+    bounds = [(i, min(i + chunk, n)) for i in range(0, n, chunk)]
+    span = max(int(off[b - 1] + sizes[b - 1] - off[a]) for a, b in bounds)
+    d_pix = [torch.empty(span, dtype=torch.int16, device=dev) for _ in range(2)]
+    d_crops = torch.empty((chunk, 64, 64), dtype=torch.float32, device=dev)
+    out = dict(mse=torch.empty(n, dtype=torch.float32, device=dev), mae=torch.empty(n, dtype=torch.float32, device=dev),
+               cons_score=torch.empty(n, dtype=torch.float64, device=dev), mod_score=torch.empty(n, dtype=torch.float64, device=dev),
+               cons_pred=torch.empty(n, dtype=torch.int8, device=dev), mod_pred=torch.empty(n, dtype=torch.int8, device=dev))
+    res = {k: torch.empty(n, dtype=v.dtype, pin_memory=True) for k, v in out.items()}
+    evs = [torch.cuda.Event() for _ in range(2)]
+
+    def copy_in(ci):
+        a, b = bounds[ci]
+        lo, hi = int(off[a]), int(off[b - 1] + sizes[b - 1])
+        with torch.cuda.stream(copy_stream):
+            d_pix[ci & 1][:hi - lo].copy_(host[lo:hi], non_blocking=True)
+            evs[ci & 1].record(copy_stream)
+
+    def run():
+        copy_in(0)
+        for ci, (a, b) in enumerate(bounds):
+            if ci + 1 < len(bounds):
+                copy_in(ci + 1)            # the other buffer: its last reader (chunk ci - 1's preprocess) has returned
+            torch.cuda.current_stream().wait_event(evs[ci & 1])
+            proc.run_packed(d_pix[ci & 1], off[a:b] - off[a], hs[a:b], ws[a:b], out=d_crops[:b - a])
+            eng.screen(d_crops[:b - a], out={k: v[a:b] for k, v in out.items()}, out_device=True)
+        for k in out:
+            res[k].copy_(out[k], non_blocking=True)
+        torch.cuda.synchronize()
+
+    try:
+        run()                              # warm-up (allocations, first-touch of the pinned pages)
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+    finally:
+        proc.close()
+    return dict(value=round(n / dt, 1), unit="cells/s", wall_s=round(dt, 4), crops=n, chunk_crops=chunk,
+                h2d_bytes_per_cell=round(2.0 * total / n, 1), d2h_bytes_per_cell=18,
+                h2d_gbs=round(2.0 * total / dt / 1e9, 2),
+                workload="%d raw uint16 crops, sides U[32,100] (4,096 distinct, repeated), pinned host -> cs_preprocess -> cs_screen -> host" % n,
+                anomaly_rate_conservative=round(float((res["cons_pred"] == -1).float().mean()), 4))
 
 
 def small_n_leg(eng, seed):
@@ -367,6 +491,8 @@ def main():
     eng.set_chunk(args.chunk)
 
     # ---- this rank's shard of the global synthetic batch, generated in HBM
+    if args.cells <= 0:
+        args.cells = 1_000_000 if world == 1 else 1_250_000          # BASELINE.json configs[2] | configs[3] (10 M over 8 GPUs)
     n_total = args.cells * world
     lo, hi = csdist.shard_range(n_total, rank, world)
     n_local = hi - lo
@@ -499,10 +625,15 @@ def main():
             "metric": "cells/sec screened (CAE fwd + recon-MSE + SVM score), 64x64",
             "value": round(value, 1), "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: screening inference, %d synthetic 64x64 crops per GPU resident in HBM, "
-                                    "CAE fwd + recon MSE/MAE + RobustScaler + PCA(100) + 2x OCSVM score on device" % args.cells)
-                                   + ("" if world == 1 else "; configs[3] layout: contiguous shards, RCCL gather of per-cell scores"),
+            "vs_baseline": None,
+            "dtype": "f32 (results in the fp32 error class; the contractions run as split 16-bit products on the matrix pipe, fp32 accumulate: "
+                     "conv2/4/5/6 as 2 fp16 terms x 3 products with exact power-of-two scales, conv1/conv3/PCA as 3 bf16 terms x 6 products; "
+                     "SVM fp64; exact_fp32 = the fp32-MFMA form)",
+            "data": "synthetic",
+            "config": {"workload": (("BASELINE.json configs[2]: screening inference, %d synthetic 64x64 crops on one GPU, resident in HBM, " % args.cells) if world == 1 else
+                                    ("BASELINE.json configs[3]: %d-GPU data-parallel screening, %d synthetic 64x64 crops per GPU (%d global; 10 M at 8 GPUs), "
+                                     "contiguous shards resident in HBM, RCCL gather of per-cell scores, " % (world, args.cells, n_total)))
+                                   + "CAE fwd + recon MSE/MAE + RobustScaler + PCA(100) + 2x OCSVM score on device",
                        "cells_per_gpu": args.cells, "global_cells": n_total, "chunk_cells": args.chunk,
                        "n_sv": [int(det.conservative.n_sv), int(det.moderate.n_sv)], "detector_train_cells": args.train_cells,
                        "weights": "random init (Glorot, non-trivial BN), seed %d" % args.seed,
@@ -516,7 +647,7 @@ def main():
                            "executed_bf16_mfma_flop_per_cell": int(exec_bf16_flop_per_cell),
                            "tflops_algorithmic": round(value * FLOP_PER_CELL / 1e12 / world, 3),
                            "note": "executed = the conv kernels' MFMA counts per cell: v_mfma_f32_16x16x4_f32 x 2,048 FLOP (conv1+conv2, conv3, conv7's contraction) "
-                                   "and v_mfma_f32_16x16x32_bf16 x 16,384 FLOP (conv4, conv5, conv6: the fp32 contraction as six bf16 products); "
+                                   "and the 16-bit forms v_mfma_f32_16x16x32_{bf16,f16} x 16,384 FLOP (the fp32 contraction as six bf16 or three fp16 products); "
                                    "algorithmic = the reference graph's 100.27 MFLOP/cell",
                            "hbm_gbs_algorithmic": round(value * BYTES_PER_CELL / 1e9 / world, 2),
                            "frac_hbm_peak": round(value * BYTES_PER_CELL / 1e9 / world / HBM_PEAK_GBS, 5),
@@ -554,7 +685,16 @@ def main():
                 line["small_n"] = small_n_leg(eng, args.seed)
             except Exception as e:  # noqa: BLE001 - an extra leg never costs the headline line
                 line["small_n"] = {"error": repr(e)}
+            try:
+                line["exact_fp32"] = exact_fp32_leg(weights, det, x, out, args, local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["exact_fp32"] = {"error": repr(e)}
             del x
+            torch.cuda.empty_cache()
+            try:
+                line["e2e_raw"] = e2e_raw_leg(eng, args.raw_crops, args.seed, local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["e2e_raw"] = {"error": repr(e)}
             torch.cuda.empty_cache()
             try:
                 line["train_leg"] = train_leg(args.train_steps, local_rank, args.seed)

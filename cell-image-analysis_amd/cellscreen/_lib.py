@@ -47,6 +47,9 @@ class CSDetectorParams(C.Structure):
                 ("conservative", CSOcsvmParams), ("moderate", CSOcsvmParams)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64)      # cs_allgather_fn
+
+
 class CSTrainCfg(C.Structure):
     _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
@@ -107,9 +110,13 @@ SIGNATURES = {
     "cs_train_free": (None, [_P]),
     "cs_train_wait_stream": (_I, [_P, _P]),
     "cs_train_step": (_I, [_P, _P, _P, _L, _I, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cs_train_step_async": (_I, [_P, _P, _P, _L, _I, C.c_float]),
+    "cs_train_inputs_consumed": (_I, [_P, _P]),
+    "cs_train_read_metrics": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L), _I]),
     "cs_train_forward_backward": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_apply": (_I, [_P, C.c_float]),
     "cs_train_set_grad_buffer": (_I, [_P, _P]),
+    "cs_train_set_sync_bn": (_I, [_P, _P, _P, _P, _L, _I, _I]),
     "cs_train_eval": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_augment": (_I, [_P, _P, _L, _P, _P, _I]),
     "cs_train_export": (_I, [_P, _P, _P, _P]),
@@ -178,6 +185,21 @@ def order_after_torch(wait_fn, handle, *buffers):
         return
     import torch
     check(wait_fn(handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
+def order_torch_after(signal_fn, handle, *buffers):
+    """The other direction: torch's current stream waits for the point the library has recorded on its own stream (the input
+    copies of an asynchronous training step, the kernel behind a device-side augmentation), so that torch neither reads a
+    result early nor hands the memory of a batch the library has not consumed yet to a later allocation."""
+    dev = None
+    for b in buffers:
+        if b is not None and not isinstance(b, np.ndarray) and getattr(b, "is_cuda", False):
+            dev = b.device
+            break
+    if dev is None:
+        return
+    import torch
+    check(signal_fn(handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 def mem_kind(a) -> int:

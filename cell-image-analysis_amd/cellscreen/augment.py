@@ -104,6 +104,39 @@ class ImageDataGenerator:
             a.flip_h, a.flip_v = int(p["flip_h"]), int(p["flip_v"])
         return arr
 
+    # ---- a whole batch at once ----------------------------------------------------------------------
+    AFFINE_DTYPE = np.dtype([("m", np.float64, 4), ("off", np.float64, 2), ("identity", np.int32), ("flip_h", np.int32),
+                             ("flip_v", np.int32), ("reserved", np.int32)])
+
+    def random_transforms(self, n: int, img_shape, rng) -> np.ndarray:
+        """n independent draws as one packed array of cs_aug_affine (what Trainer.augment takes): the same distributions and the
+        same matrix algebra as get_random_transform + affine, evaluated with numpy over the batch -- a fit() epoch draws
+        1,250 x 32 transforms and the per-image Python path costs more host time than the training step costs the GPU.  The
+        draws come in a different ORDER from the stream than Keras's per-image loop takes them (all thetas first, ...), which
+        only matters to someone replaying a particular seed."""
+        h, w = float(img_shape[0]), float(img_shape[1])
+        uni = lambda lo, hi: rng.uniform(lo, hi, n)                                  # noqa: E731
+        theta = np.deg2rad(uni(-self.rotation_range, self.rotation_range)) if self.rotation_range else np.zeros(n)
+        tx = uni(-self.height_shift_range, self.height_shift_range) * (h if self.height_shift_range < 1 else 1.0) if self.height_shift_range else np.zeros(n)
+        ty = uni(-self.width_shift_range, self.width_shift_range) * (w if self.width_shift_range < 1 else 1.0) if self.width_shift_range else np.zeros(n)
+        if self.zoom_range[0] == 1 and self.zoom_range[1] == 1:
+            zx = zy = np.ones(n)
+        else:
+            zx, zy = uni(self.zoom_range[0], self.zoom_range[1]), uni(self.zoom_range[0], self.zoom_range[1])
+        fh = (rng.uniform(0.0, 1.0, n) < 0.5) & self.horizontal_flip
+        fv = (rng.uniform(0.0, 1.0, n) < 0.5) & self.vertical_flip
+        c, s_ = np.cos(theta), np.sin(theta)
+        # (rotation . shift . zoom): linear part R Z, translation R t; then moved to the image centre: off = o + R t - (R Z) o
+        m00, m01, m10, m11 = c * zx, -s_ * zy, s_ * zx, c * zy
+        ox, oy = h / 2 + self.center, w / 2 + self.center
+        out = np.zeros(n, self.AFFINE_DTYPE)
+        out["m"][:, 0], out["m"][:, 1], out["m"][:, 2], out["m"][:, 3] = m00, m01, m10, m11
+        out["off"][:, 0] = ox + (c * tx - s_ * ty) - (m00 * ox + m01 * oy)
+        out["off"][:, 1] = oy + (s_ * tx + c * ty) - (m10 * ox + m11 * oy)
+        out["identity"] = (theta == 0) & (tx == 0) & (ty == 0) & (zx == 1) & (zy == 1)
+        out["flip_h"], out["flip_v"] = fh, fv
+        return out
+
     # ---- flow ---------------------------------------------------------------------------------
     def random_batch(self, trainer, batch, rng=np.random):
         """What one `next(datagen.flow(x, ...))` does to x: one independent draw per image.

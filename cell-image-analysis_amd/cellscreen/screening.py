@@ -43,8 +43,9 @@ class ProductionMutantScreening:
                 return self.cell_extractor(image_path)
             if image_path.endswith(".npy"):
                 cells = np.load(image_path)
-                if cells.ndim != 3 or cells.shape[1:] != spec.INPUT_HW:
-                    raise ValueError(f"expected (N,64,64) crops, got {cells.shape}")
+                hw = (self.engine.info.height, self.engine.info.width)      # 64 x 64 for the reference graph
+                if cells.ndim != 3 or cells.shape[1:] != hw:
+                    raise ValueError(f"expected (N,{hw[0]},{hw[1]}) crops, got {cells.shape}")
                 stats = [{"mean_intensity": float(np.mean(c)), "std_intensity": float(np.std(c))} for c in cells]
                 return list(cells), stats
             raise NotImplementedError("StarDist cell extraction is out of scope; pass cell_extractor= or use .npy crop files")

@@ -74,6 +74,8 @@ class Trainer:
         h = C.c_void_p()
         L.check(self._lib.cs_train_create(C.byref(w), C.byref(cfg), device_id, C.byref(h)))
         self._h = h
+        self._device_id = device_id
+        self._sync = None
         self.bn_eps = init.bn_eps
         # the architecture: the reference graph, or any other instance of its layer grammar (csrc/train_generic.hip)
         self.channels, self.input_hw, self.n_enc = tuple(init.channels), tuple(init.input_hw), init.n_enc
@@ -112,6 +114,24 @@ class Trainer:
         L.check(self._lib.cs_train_step(self._h, xp, yp, n, kind, lr, C.byref(loss), C.byref(mae)))
         return loss.value, mae.value
 
+    def step_async(self, x, y, lr: float = spec.ADAM_LR) -> None:
+        """cs_train_step_async: the same batch enqueued without a host synchronisation; its loss / mae go into the running
+        sums read_metrics() returns (Keras's epoch metrics: the mean over the epoch's batches)."""
+        xb, xp, kind, n = self._buf(x)
+        yb, yp, kind2, n2 = self._buf(y)
+        assert kind == kind2 and n == n2
+        L.check(self._lib.cs_train_step_async(self._h, xp, yp, n, kind, lr))
+        L.order_torch_after(self._lib.cs_train_inputs_consumed, self._h, xb, yb)    # torch may reuse the batch's memory only after the copies
+
+    def read_metrics(self, reset: bool = True) -> Tuple[float, float, int]:
+        """(mean loss, mean mae, steps) over the step_async calls since the last reset: one host round trip."""
+        lo, ma, st = C.c_double(), C.c_double(), C.c_int64()
+        L.check(self._lib.cs_train_read_metrics(self._h, C.byref(lo), C.byref(ma), C.byref(st), 1 if reset else 0))
+        return lo.value, ma.value, st.value
+
+    def reset_metrics(self) -> None:
+        self.read_metrics(reset=True)
+
     def forward_backward(self, x, y) -> Tuple[float, float]:
         xb, xp, kind, n = self._buf(x)
         yb, yp, kind2, n2 = self._buf(y)
@@ -132,7 +152,10 @@ class Trainer:
             import torch
             out = torch.empty_like(xb)
             op = out.data_ptr()
-        L.check(self._lib.cs_train_augment(self._h, xp, n, C.cast(transforms, C.c_void_p), op, kind))
+            L.order_after_torch(self._lib.cs_train_wait_stream, self._h, out)
+        tp = C.c_void_p(transforms.ctypes.data) if isinstance(transforms, np.ndarray) else C.cast(transforms, C.c_void_p)
+        L.check(self._lib.cs_train_augment(self._h, xp, n, tp, op, kind))
+        L.order_torch_after(self._lib.cs_train_inputs_consumed, self._h, out if kind != L.CS_MEM_HOST else None)   # device output: torch reads it after the kernel
         return out
 
     def apply(self, lr: float = spec.ADAM_LR):
@@ -140,6 +163,39 @@ class Trainer:
         still be writing (torch orders its current stream after the collective): the update is ordered after it."""
         L.order_after_torch(self._lib.cs_train_wait_stream, self._h, self._grad_tensor)
         L.check(self._lib.cs_train_apply(self._h, lr))
+
+    def set_sync_bn(self, all_gather, rank: int, world: int):
+        """cs_train_set_sync_bn: BatchNormalization statistics over the whole batch when it is split over `world` ranks.
+        all_gather(buf, floats_per_rank) must fill buf[0 : world * floats_per_rank] (a torch CUDA float32 tensor in which
+        this rank's slot [rank * fpr, (rank + 1) * fpr) is already written) and return when that is complete on the device;
+        None switches the synchronisation off."""
+        if all_gather is None:
+            L.check(self._lib.cs_train_set_sync_bn(self._h, None, None, None, 0, 0, 1))
+            self._sync = None
+            return
+        import torch
+        buf = torch.zeros(world * 3 * 64, dtype=torch.float32, device=torch.device("cuda", self._device_id))
+
+        def hook(_ctx, fpr):
+            try:
+                all_gather(buf, int(fpr))
+                return 0
+            except Exception as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+                self._sync_error = e
+                return 1
+        cb = L.ALLGATHER_FN(hook)
+        L.check(self._lib.cs_train_set_sync_bn(self._h, C.cast(cb, C.c_void_p), None, buf.data_ptr(), buf.numel(), rank, world))
+        self._sync = (cb, buf)                # keep the callback and the buffer alive as long as the library may call / write them
+
+    def enable_sync_bn(self, dist, rank: int, world: int, group=None):
+        """The same over torch.distributed (backend nccl = RCCL over xGMI): one all_gather_into_tensor per sync point."""
+        import torch
+
+        def all_gather(buf, fpr):
+            mine = buf[rank * fpr:(rank + 1) * fpr].clone()
+            dist.all_gather_into_tensor(buf[:world * fpr], mine, group=group)
+            torch.cuda.current_stream(buf.device).synchronize()
+        self.set_sync_bn(all_gather, rank, world)
 
     def use_grad_tensor(self, t):
         """Gradients are written into this torch CUDA float32 tensor (n_trainable elements), so

@@ -20,9 +20,17 @@ and text reports (:304-326, 345-392, 448-478).
 * `data_parallel=True` (one process per GPU under torch.distributed): every rank draws the SAME shuffled order and
   trains on its 1/W slice of each global batch of `batch_size` (32 cells in total, as the reference's single
   process sees); the flat 337 KB gradient is averaged with one RCCL all-reduce per step (cs_train_forward_backward
-  -> all-reduce -> cs_train_apply) so every rank holds identical weights.  BatchNormalization statistics are
-  computed per rank over its slice (what Keras does under data parallelism without SyncBatchNormalization): with
-  W > 1 that is a documented deviation from the reference's single batch of 32.
+  -> all-reduce -> cs_train_apply) so every rank holds identical weights.  `sync_bn=True` (the default) makes the
+  BatchNormalization batch statistics those of the WHOLE batch of 32, as the reference's single process computes them
+  (CAE_improved_modeltrain.py:192-213 with batch_size=32 at :287): the per-rank {n, mean, M2} triples of a layer are
+  all-gathered and merged, and so are the two sums of its backward pass (cellscreen/trainer.py, Trainer.enable_sync_bn);
+  `sync_bn=False` keeps per-rank statistics over the rank's slice (what Keras does under data parallelism without
+  SyncBatchNormalization) -- a deviation from the reference.  Either way the end of every epoch makes the ranks identical
+  before anything is decided: the moving statistics are averaged over the ranks and rank 0's validation loss is what every
+  rank's callbacks see, so EarlyStopping and ReduceLROnPlateau fire on the same epoch everywhere.
+* Any instance of the layer grammar trains: `create_improved_autoencoder(input_shape)` is generic in the reference
+  (:184), and `train_autoencoder` builds the model for the shape of the crops it is given (the reference graph on its tuned
+  kernels, other sizes on the run-time-shaped ones of csrc/train_generic.hip).
 """
 from __future__ import annotations
 
@@ -52,7 +60,7 @@ class History:
 class ImprovedAnomalyDetectionTraining:
     def __init__(self, output_dir: str, device_id: int = 0, seed: int = 42, epochs: int = spec.EPOCHS,
                  batch_size: int = spec.BATCH_SIZE, augment="reference", verbose: int = 1,
-                 detector_fit: str = "device", data_parallel: bool = False, keras_version: int = 3):
+                 detector_fit: str = "device", data_parallel: bool = False, keras_version: int = 3, sync_bn: bool = True):
         self.output_dir = output_dir                       # CAE_improved_modeltrain.py:26-27
         os.makedirs(output_dir, exist_ok=True)
         self.device_id = device_id
@@ -64,6 +72,7 @@ class ImprovedAnomalyDetectionTraining:
             raise ValueError("detector_fit must be 'device' (csrc/fit.hip) or 'sklearn' (the reference's library on the host)")
         self.detector_fit = detector_fit
         self.data_parallel = bool(data_parallel)
+        self.sync_bn = bool(sync_bn)
         self.keras_version = int(keras_version)            # EarlyStopping's restore rule differs (callbacks.py)
         self._autoencoder: Optional[CAEWeights] = None     # what the reference keeps in the Keras objects it returns
         self._best_autoencoder: Optional[CAEWeights] = None
@@ -72,10 +81,12 @@ class ImprovedAnomalyDetectionTraining:
     def create_improved_autoencoder(self, input_shape=(64, 64, 1)):
         """:184-229.  Returns (autoencoder, encoder) as the reference does: the initial weight set (Glorot-uniform
         kernels, zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving var 1 -- the Keras defaults) and its encoder
-        half, which shares the same arrays as the reference's two Models share their layers."""
-        if tuple(input_shape[:2]) != spec.INPUT_HW:
-            raise NotImplementedError("this build trains the reference's 64x64 graph")
-        ae = synth.random_cae(seed=self.seed, trivial_bn=True)
+        half, which shares the same arrays as the reference's two Models share their layers.  input_shape is generic as in
+        the reference: the same seven convs on another crop size (whether the kernels take that size is decided where the
+        weights meet them: Trainer / Engine raise CS_ERR_UNSUPPORTED with the reason)."""
+        if len(input_shape) not in (2, 3) or (len(input_shape) == 3 and input_shape[2] != 1):
+            raise ValueError(f"input_shape {tuple(input_shape)}: the reference's model takes one grey-level channel")
+        ae = synth.random_cae(seed=self.seed, hw=(int(input_shape[0]), int(input_shape[1])), trivial_bn=True)
         return ae, ae.encoder_half()
 
     # ---- training ------------------------------------------------------------------------
@@ -105,15 +116,17 @@ class ImprovedAnomalyDetectionTraining:
         if self.batch_size % world:
             raise ValueError(f"batch_size {self.batch_size} does not split over {world} ranks")
         local_b = self.batch_size // world
-        dev = torch.device("cuda", self.device_id)
+        dev = torch.device("cuda", self.device_id) if torch.cuda.is_available() else torch.device("cpu")   # no GPU: Trainer() below refuses
         Xd = torch.from_numpy(np.ascontiguousarray(X_train)).to(dev)               # resident: batches are device-side gathers
         Xv = torch.from_numpy(np.ascontiguousarray(X_val)).to(dev)
-        ae0, _ = self.create_improved_autoencoder()
+        ae0, _ = self.create_improved_autoencoder(X.shape[1:3] + (1,))             # :257 (the reference's crops are 64x64)
         tr = Trainer(ae0, device_id=self.device_id)
         grad = None
         if world > 1:
             grad = torch.zeros(tr.n_trainable, dtype=torch.float32, device=dev)
             tr.use_grad_tensor(grad)
+            if self.sync_bn:
+                tr.enable_sync_bn(dist, rank, world)
         augment = self.augment
         if augment == "reference":                                                  # datagen of :246-254
             from .augment import reference_augment
@@ -139,19 +152,32 @@ class ImprovedAnomalyDetectionTraining:
                         dist.all_reduce(grad, op=dist.ReduceOp.SUM)
                         grad /= world
                         tr.apply(lr)                                                # ordered after the all-reduce (Trainer.apply)
+                        tl += l; tm += m
                     else:
-                        l, m = tr.step(xb, yb, lr)
-                    tl += l; tm += m
-                vl, vm = tr.evaluate(Xv, Xv)                                        # validation_data=(X_val, X_val) (:290)
-                if world > 1:                                                       # rank-mean of the training metrics, as one process would log
+                        tr.step_async(xb, yb, lr)                                   # no host round trip: the scalars are summed on the device
+                if world > 1:
+                    # what one process would log: the rank-mean of the training metrics; and ONE set of moving statistics
+                    # (identical already under sync_bn; per-rank otherwise), so that every rank validates the same model
                     t = torch.tensor([tl, tm], dtype=torch.float64, device=dev)
                     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    tl, tm = (float(v) / world for v in t.tolist())
-                for k, v in (("loss", tl / max(steps, 1)), ("mae", tm / max(steps, 1)), ("val_loss", vl), ("val_mae", vm), ("lr", lr),
-                             ("learning_rate", lr)):
+                    tl, tm = (float(v) / world / max(steps, 1) for v in t.tolist())
+                    params, moving = tr.export_flat()
+                    mv = torch.from_numpy(moving).to(dev)
+                    dist.all_reduce(mv, op=dist.ReduceOp.SUM)
+                    tr.load_flat(None, (mv / world).cpu().numpy())
+                else:
+                    tl, tm, _ = tr.read_metrics(reset=True)                         # Keras's epoch metrics: the mean over the batches
+                vl, vm = tr.evaluate(Xv, Xv)                                        # validation_data=(X_val, X_val) (:290)
+                if world > 1:
+                    # the callbacks act on val_loss: every rank must see the SAME number or the ranks stop / halve the rate on
+                    # different epochs (a different stop epoch leaves the others waiting in an all-reduce for ever)
+                    v = torch.tensor([vl, vm], dtype=torch.float64, device=dev)
+                    dist.broadcast(v, src=0)
+                    vl, vm = (float(q) for q in v.tolist())
+                for k, v in (("loss", tl), ("mae", tm), ("val_loss", vl), ("val_mae", vm), ("lr", lr), ("learning_rate", lr)):
                     hist.history[k].append(float(v))
                 if self.verbose:
-                    print(f"Epoch {epoch + 1}/{self.epochs} - loss: {tl / max(steps, 1):.6f} - mae: {tm / max(steps, 1):.6f} - val_loss: {vl:.6f} - val_mae: {vm:.6f} - learning_rate: {lr:.2e}")
+                    print(f"Epoch {epoch + 1}/{self.epochs} - loss: {tl:.6f} - mae: {tm:.6f} - val_loss: {vl:.6f} - val_mae: {vm:.6f} - learning_rate: {lr:.2e}")
                 act = cb.on_epoch_end(epoch, vl)
                 if act.snapshot_best_weights:                                       # EarlyStopping's model.get_weights()
                     best_flat = tr.export_flat()
@@ -202,6 +228,8 @@ class ImprovedAnomalyDetectionTraining:
         """A full weight set around an encoder-only one (zero decoder): the engine computes encoder features from it."""
         n = spec.N_ENC
         ch = spec.CHANNELS
+        if encoder.n_enc != n or tuple(encoder.channels[:n]) != tuple(ch[:n]):
+            raise ValueError("an encoder-only weight set of another architecture needs its autoencoder passed alongside")
         ks, bs = list(encoder.kernels), list(encoder.biases)
         g, b, m, v = list(encoder.bn_gamma), list(encoder.bn_beta), list(encoder.bn_mean), list(encoder.bn_var)
         cin = ch[n - 1]

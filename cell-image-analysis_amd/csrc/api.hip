@@ -34,6 +34,10 @@ struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf c12w1, c12w1x3; // conv1's fragments for the fused kernel (negated for filters with a negative BN scale); x3: its bf16 form
     DevBuf c3x3, c4x3, c5x3, c6x3;   // conv3's Winograd U / conv4's / conv5's / conv6's weights as three bf16 planes
+    DevBuf c4h2, c5h2, c6h2;         // conv4's / conv5's / conv6's (folded) weights as two fp16 planes (the *_h2 kernels) ...
+    float c4h2_inv = 1.0f, c5h2_inv = 1.0f, c6h2_inv = 1.0f;   // ... and 1 / their power-of-two scales
+    DevBuf c12h2;          // the same U as two fp16 planes (C2H form of the fused kernel) ...
+    float c12h2_inv = 1.0f, p1a = 0.0f, p1b = 0.0f;   // ... 1 / their scale, and the bound max|p1| <= p1a max|x| + p1b
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
     DevBuf winoup[6];      // conv5 / conv6 as four Winograd F(2x2,2x2) phase convs (index = layer)
     DevBuf wfrag[6];       // MFMA B fragments of convs 1..6
@@ -81,6 +85,10 @@ struct cs_model {
     bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
     bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
+    bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
+    bool h2conv6 = getenv("CS_NO_FP16X2_CONV6") == nullptr; // A/B knob: conv6 (in the fused conv6 + conv7 kernel) alone
+    bool h2conv2 = getenv("CS_NO_FP16X2_CONV2") == nullptr; // conv2 inside the fused conv1 + conv2 kernel alone
+    bool h2conv4 = getenv("CS_NO_FP16X2_CONV4") == nullptr, h2conv5 = getenv("CS_NO_FP16X2_CONV5") == nullptr;   // conv4 / conv5 alone
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
     bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
@@ -255,6 +263,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             pack_conv4_bf16x3(w->kernel[l], planes.data());
             rc = upload(set.c4x3, planes.data(), planes.size() * sizeof(uint16_t));
             if (rc) return rc;
+            std::vector<uint16_t> h2(pack_conv4_f16x2(nullptr, nullptr, nullptr));
+            pack_conv4_f16x2(w->kernel[l], h2.data(), &set.c4h2_inv);
+            rc = upload(set.c4h2, h2.data(), h2.size() * sizeof(uint16_t));
+            if (rc) return rc;
         }
         if (l == 4) {
             std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
@@ -263,6 +275,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             pack_conv5_bf16x3(weff.data(), planes.data());
             rc = upload(set.c5x3, planes.data(), planes.size() * sizeof(uint16_t));
             if (rc) return rc;
+            std::vector<uint16_t> h2(pack_conv5_f16x2(nullptr, nullptr, nullptr));
+            pack_conv5_f16x2(weff.data(), h2.data(), &set.c5h2_inv);
+            rc = upload(set.c5h2, h2.data(), h2.size() * sizeof(uint16_t));
+            if (rc) return rc;
         }
         if (l == 5) {
             std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
@@ -270,6 +286,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             std::vector<uint16_t> planes(pack_conv6_bf16x3(nullptr, nullptr));
             pack_conv6_bf16x3(weff.data(), planes.data());
             rc = upload(set.c6x3, planes.data(), planes.size() * sizeof(uint16_t));
+            if (rc) return rc;
+            std::vector<uint16_t> h2(pack_conv6_f16x2(nullptr, nullptr, nullptr));
+            pack_conv6_f16x2(weff.data(), h2.data(), &set.c6h2_inv);
+            rc = upload(set.c6h2, h2.data(), h2.size() * sizeof(uint16_t));
             if (rc) return rc;
         }
         if (l == 0) {
@@ -281,11 +301,16 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             pack_conv12_conv1_x3(w->kernel[l], ep.data() + cout, wx.data());
             rc = upload(set.c12w1x3, wx.data(), wx.size() * sizeof(unsigned int));
             if (rc) return rc;
+            pack_conv12_p1_bound(w->kernel[l], ep.data(), &set.p1a, &set.p1b);
         }
         if (l == 1) {
             tmp.resize(pack_conv12_fragments(nullptr, nullptr, nullptr));
             pack_conv12_fragments(w->kernel[l], ep.data() + cout, tmp.data());
             rc = upload(set.c12, tmp.data(), tmp.size() * sizeof(float));
+            if (rc) return rc;
+            std::vector<unsigned int> uh(pack_conv12_fragments_h2(nullptr, nullptr, nullptr, nullptr));
+            pack_conv12_fragments_h2(w->kernel[l], ep.data() + cout, uh.data(), &set.c12h2_inv);
+            rc = upload(set.c12h2, uh.data(), uh.size() * sizeof(unsigned int));
             if (rc) return rc;
         }
     }
@@ -509,16 +534,24 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     const bool fused = m->fuse67 && m->use_wino && m->wino6 && first <= 5 && last >= 6 && !recon;
     // conv1 + conv2 as one kernel whenever p1 itself is not asked for (it is never written then)
     const bool fused12 = m->fuse12 && m->use_wino && first == 0 && last >= 1;
-    if (fused12)
+    if (fused12) {
+        const bool c1x3 = m->bf16x3 && m->x3conv1, c2h = c1x3 && m->fp16x2 && m->h2conv2;
         LAUNCH(K_CONV12_FUSED, nc,
                launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
-                                   m->act[1].as<float>(), nc, m->stream, (m->bf16x3 && m->x3conv1) ? set.c12w1x3.as<unsigned int>() : nullptr));
+                                   m->act[1].as<float>(), nc, m->stream, c1x3 ? set.c12w1x3.as<unsigned int>() : nullptr,
+                                   c2h ? set.c12h2.as<unsigned int>() : nullptr, set.p1a, set.p1b, set.c12h2_inv));
+    }
     if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / A-B knob) needs p1 in HBM
         int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
         if (rc) return rc;
     }
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        if (l == 4 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv5) {
+            LAUNCH(K_CONV5, nc,
+                   launch_conv5_h2(in, set.c5h2.as<uint16_t>(), set.c5h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
         if (l == 4 && m->bf16x3 && m->x3conv5) {
             LAUNCH(K_CONV5, nc,
                    launch_conv5_bf16x3(in, set.c5x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
@@ -539,6 +572,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
                    launch_conv_wino_cs(l, in, set.winocs[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
+        if (l == 3 && m->bf16x3 && m->fp16x2 && m->h2conv4) {
+            LAUNCH(K_CONV4, nc,
+                   launch_conv4_h2(in, set.c4h2.as<uint16_t>(), set.c4h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
         if (l == 3 && m->bf16x3) {
             LAUNCH(K_CONV4, nc,
                    launch_conv4_bf16x3(in, set.c4x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
@@ -547,7 +585,12 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         LAUNCH(K_CONV1 + l, nc,
                launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, l == 4 || l == 5));
     }
-    if (fused && m->bf16x3 && m->x3conv6) {
+    if (fused && m->bf16x3 && m->x3conv6 && m->fp16x2 && m->h2conv6) {
+        LAUNCH(K_CONV67_FUSED, nc,
+               launch_conv67_h2(m->act[4].as<float>(), set.c6h2.as<uint16_t>(), set.c6h2_inv, set.ep[5].as<float>(), x, m->w7eff.as<float>(),
+                                m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
+        m->errparts = conv67_fused_nparts();
+    } else if (fused && m->bf16x3 && m->x3conv6) {
         LAUNCH(K_CONV67_FUSED, nc,
                launch_conv67_x3(m->act[4].as<float>(), set.c6x3.as<uint16_t>(), set.ep[5].as<float>(), x, m->w7eff.as<float>(),
                                 m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
@@ -1202,7 +1245,7 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
             case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
             case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
             case K_CONV67_FUSED: v = (m->bf16x3 && m->x3conv6) ? 512 : 4608 + 512; break;   // conv6 phases (unless on bf16 MFMAs) + conv7's 32 -> 16 contraction
-            case K_CONV12_FUSED: v = (m->bf16x3 && m->x3conv1) ? 4608 : 4608 + 1536 + 48; break;   // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct (unless on bf16 MFMAs);
+            case K_CONV12_FUSED: v = (m->bf16x3 && m->x3conv1) ? ((m->fp16x2 && m->h2conv2) ? 0 : 4608) : 4608 + 1536 + 48; break;   // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct (unless on bf16 MFMAs);
                                                                             // + the discarded fourth row of a cell's last 4-row batch
             case K_SCALER_PCA: v = (m->bf16x3 && m->x3pca) ? 0.0 : (double)m->fpad * m->cpad / 1024.0; break;
             default: v = 0.0;
@@ -1229,11 +1272,13 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
         return CS_OK;
     }
     if (m->arch.ref) {
-        if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * 6;                  // 4 tiles x 2 slices x 9 taps x 6 products
+        if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * ((m->fp16x2 && m->h2conv4) ? 3 : 6);   // 4 tiles x 2 slices x 9 taps x 6 (bf16 split) or 3 (fp16 split) products
         if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3) v = 16.0 * 4 * 2 * 2 * 6;   // 16 points x 4 tile groups x 2 slices x 2 blocks x 6
-        if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1) v = 66 * 8 * 3;      // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs
-        if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * 6;   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 products
-        if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6) v = 4.0 * 16 * 2 * 4 * 2 * 6;   // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6
+        if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1)               // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs;
+            v = 66 * 8 * 3 + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
+        if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * ((m->fp16x2 && m->h2conv5) ? 3 : 6);   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 | 3 products
+        if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6)          // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6 (bf16 split) or 3 (fp16 split)
+            v = 4.0 * 16 * 2 * 4 * 2 * ((m->fp16x2 && m->h2conv6) ? 3 : 6);
     } else if (k <= K_CONV6 && m->bf16x3) {
         const int l = k - K_CONV1;
         if (l < m->arch.n_conv && m->gae.x3[l]) {

@@ -44,8 +44,13 @@ size_t pack_wino3_x3(const float* hwio, uint16_t* dst);       // returns the num
 // conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
 // pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
 // w1x3 (optional, pack_conv12_conv1_x3): conv1 runs on bf16 MFMAs (the three bf16 planes of the crop packed along K)
+// ufrag_h2 (optional, with w1x3; pack_conv12_fragments_h2): conv2's contraction as a two-term fp16 split; p1a / p1b = pack_conv12_p1_bound,
+// inv_sw = 1 / the scale of ufrag_h2
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3 = nullptr);
+                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3 = nullptr, const unsigned int* ufrag_h2 = nullptr,
+                               float p1a = 0.0f, float p1b = 0.0f, float inv_sw = 1.0f);
+size_t pack_conv12_fragments_h2(const float* hwio, const float* bn_scale, unsigned int* dst, float* inv_sw);     // returns 32-bit words
+void pack_conv12_p1_bound(const float* hwio1, const float* ep1, float* a1, float* b1);
 size_t pack_conv12_conv1_x3(const float* hwio, const float* bn_scale, unsigned int* dst);     // returns 32-bit words
 size_t pack_conv12_fragments(const float* hwio, const float* bn_scale, float* dst);
 size_t pack_conv12_conv1_fragments(const float* hwio, const float* bn_scale, float* dst);
@@ -55,6 +60,11 @@ size_t pack_conv4_bf16x3(const float* hwio, uint16_t* dst);     // returns the n
 // conv5 (layer 4) likewise, on the folded-upsample form: weff = pack_generic_folded(32, 64, hwio, .)
 hipError_t launch_conv5_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
 size_t pack_conv5_bf16x3(const float* weff, uint16_t* dst);
+// conv4 / conv5 as a two-term fp16 split (three products; conv45_bf16x3.hip): planes + 1 / (their power-of-two scale)
+hipError_t launch_conv4_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+size_t pack_conv4_f16x2(const float* hwio, uint16_t* dst, float* inv_sw);
+hipError_t launch_conv5_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+size_t pack_conv5_f16x2(const float* weff, uint16_t* dst, float* inv_sw);
 // conv5 (layer 4) / conv6 (layer 5), the upsample-fed decoder convs, as four Winograd F(2x2,2x2) phase convs: conv_wino_up.hip
 hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
@@ -74,6 +84,14 @@ int conv67_fused_nparts();
 hipError_t launch_conv67_x3(const float* a5, const uint16_t* wplanes, const float* ep, const float* x, const float* weff_dev,
                             const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
 size_t pack_conv6_bf16x3(const float* weff, uint16_t* dst);
+// ... and as a TWO-term fp16 split (three products, power-of-two operand scales; conv_wino_up.hip has the algebra):
+// wplanes = pack_conv6_f16x2(pack_generic_folded(64, 32, hwio, .), ., &inv_sw)
+hipError_t launch_conv67_h2(const float* a5, const uint16_t* wplanes, float inv_sw, const float* ep, const float* x, const float* weff_dev,
+                            const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
+size_t pack_conv6_f16x2(const float* weff, uint16_t* dst, float* inv_sw);
+// helpers of the fp16-split packers: the power of two that puts max|w| into [2^14, 2^15), and one value's two fp16 terms
+float f16x2_weight_scale(const float* w, size_t n);
+void f16x2_split(float w, float S, uint16_t& hi, uint16_t& lo);
 
 // weff_dev: device, [16][32] effective weights (conv7_effective_weights / launch_pack_w7eff);
 // b7_dev: device, the conv's bias; errpart: [n][4][2]; recon (may be null): [n][64][64].
@@ -93,6 +111,7 @@ hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, f
 hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s);
 hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, float momentum, float* mov_mean,
                                  float* mov_var, float* stats, hipStream_t s);
+hipError_t launch_bn_stats_merge(const float* part, int G, int C, float* out /*[3][C]*/, hipStream_t s);
 hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const float* beta, const float* stats, float* a,
                            long N, int H, int W, int pool, hipStream_t s);
 // errpart / nparts / out2 (optional): also reduce the error partial sums of the forward pass to {loss, mae} (saves a launch)
@@ -109,8 +128,9 @@ hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats,
 hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
                         hipStream_t s);
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);
+// alpha_dev == NULL: the step size is alpha_val; macc (optional): {sum loss, sum mae, batches} += batch_scal's {loss, mae}, 1
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, const float* alpha_dev, float b1, float b2, float eps,
-                       hipStream_t s);
+                       hipStream_t s, float alpha_val = 0.0f, const float* batch_scal = nullptr, double* macc = nullptr);
 // run-time-shaped conv for non-reference architectures (conv_generic.hip)
 // GEN_EPI_RELU (bias -> ReLU, full resolution) and GEN_EPI_PLAIN (the raw sums; ep may be NULL) serve training:
 // forward with BatchNormalization in batch mode, and the backward-data convs (train_generic.hip)

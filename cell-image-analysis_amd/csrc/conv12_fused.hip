@@ -29,9 +29,11 @@
 // 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008 | conv1 fragments (fp32 and bf16 forms) and epilogue constants 9,344.
 #include "common.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 namespace cs {
 
@@ -53,7 +55,8 @@ constexpr int OFF_EP1 = OFF_B1 + 2 * 3 * 64 * 4;       // conv1 epilogue {bias, 
 constexpr int OFF_EP2 = OFF_EP1 + 32 * 16;             // conv2 epilogue, same
 constexpr int OFF_B1X = OFF_EP2 + 64 * 16;             // conv1 on bf16 MFMAs: B fragments [2 slices][3 MFMAs][64 lanes][8 bf16]
 constexpr int OFF_W9 = OFF_B1X + 2 * 3 * 64 * 16;      // ... and the fp32 weight of tap (2,2) per channel
-constexpr int LDS_BYTES = OFF_W9 + 32 * 4;
+constexpr int OFF_XMAX = OFF_W9 + 32 * 4;               // C2H: max|x| of the crop staged for the next cell (one word; 16 bytes kept)
+constexpr int LDS_BYTES = OFF_XMAX + 16;
 constexpr int REC_ROWS = 20;                           // crop rows of a group as bf16 records, kept in the (then dead) V area
 static_assert(REC_ROWS * INP_STRIDE * 8 <= V_BYTES, "records live in the V area");
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_RING % 16 == 0 && OFF_E2 % 16 == 0 && OFF_INP % 16 == 0, "LDS map");
@@ -122,6 +125,43 @@ __device__ __forceinline__ u32x2 c1_record(float v)
     return u32x2{d0, d1};
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// max over the 16 lanes of a DPP row of non-negative float bit patterns
+__device__ __forceinline__ unsigned int c12_rowmax(unsigned int m)
+{
+    unsigned int o;
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [1,0,3,2]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [2,3,0,1]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:4
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:8
+    return m;
+}
+__device__ __forceinline__ unsigned int c12_absmax8(const f32x4& a, const f32x4& b)
+{
+    // scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 whatever the index (clang 19, ROCm 7.2)
+    const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(a2), fabsf(a3))), fmaxf(fmaxf(fabsf(b0), fabsf(b1)), fmaxf(fabsf(b2), fabsf(b3))));
+    return __builtin_bit_cast(unsigned int, m);
+}
+
+// C2H: conv2's contraction M = V U (P3) as a TWO-term fp16 split on v_mfma_f32_16x16x32_f16 (conv_wino_up.hip, conv67_h2_kernel, has
+// the algebra and the hardware facts; tests/study_split_fp16.py the error: p2 1.1e-6 of its range, the fp32 chain 1.2e-6).  A
+// transform point's 32 channels are ONE K = 32 instruction, so 36 points x 4 tile groups x 4 filter slices x 3 products = 1,728
+// MFMAs of 16 cycles per cell replace 4,608 fp32 ones of 32; U as two fp16 planes is the same 144 VGPRs per wave.
+//   scale   |V| <= 100 max|p1| (B^T of F(4,3) has absolute row sums <= 10), and max|p1| <= a1 max|x| + b1 with a1, b1 from
+//           conv1's weights and BN (host, pack_conv12_p1_bound): S puts 100 (a1 max|x| + b1) into [2^14, 2^15), max|x| is taken
+//           where the crop is staged (once per cell).  The ring holds S p1 at no cost (conv1's BN constants times S: a
+//           power of two commutes with every rounding), V = B^T d B comes out scaled, U carries the layer's S_w from the host, and
+//           the conv2 epilogue's sign factor carries 1 / (S S_w).
+//   P2      a thread splits its 36 values; the 16-byte A fragments want 8 CHANNELS of one plane, a thread owns one channel: the
+//           [hi | lo] dword goes to the neighbouring lane (channel ^ 1) by DPP and one v_perm_b32 leaves the even lane with
+//           [hi c | hi c+1] and the odd lane with [lo c | lo c+1] -- 36 ds_write_b32 as before.
+//   V       [point][tile 16][slot 8 ^ ((tile >> 1) & 7)][16 B]: slots 0-3 = hi of channels 8 kq .., 4-7 = lo; the XOR makes every
+//           16-lane group of P3's ds_read_b128 land on 16 distinct slots, and a half wave's writes cover one tile's 128 bytes.
+//   P3      per point two ds_read_b128 and three MFMAs (hi lo, lo hi, hi hi in that order on one accumulator: small terms first).
 // C1X3: conv1 (P1) on the bf16 matrix pipe.  Its K is only 9 taps, so the three bf16 planes of the input are packed ALONG K:
 // a pixel is a 4-slot record [x1, x2, x3, x1], a K = 32 fragment is eight taps' records, and the six split products become THREE
 // MFMAs on the same A registers, one per order of magnitude: B = [w1, 0, 0, 0] per tap gives x1 w1, [w2, w1, 0, 0] gives
@@ -133,11 +173,12 @@ __device__ __forceinline__ u32x2 c1_record(float v)
 // 48 cycles of matrix time per 16 pixels x 16 filters instead of 96, and these MFMAs leave issue slots to the pooling
 // epilogue of the SIMD's other wave.  The records of the rows a group needs are made in P4 of the previous group (the V area
 // is dead from the end of P3 to the start of P2) from the fp32 crop, which stays for the ninth tap.
-template <bool DIAG, bool C1X3>
+template <bool DIAG, bool C1X3, bool C2H>
 __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1frag,
                                                               const float* __restrict__ ep1, const float* __restrict__ ufrag,
                                                               const float* __restrict__ ep2, float* __restrict__ p2, long n_cells,
-                                                              unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3)
+                                                              unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3,
+                                                              float p1a, float p1b, float inv_sw)
 {
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,10 +221,27 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         const int srow = tid >> 4, sc16 = tid & 15;
         const float* src = x + (size_t)blockIdx.x * 4096 + srow * 64 + 4 * sc16;
         float* dst = inp + (srow + 1) * INP_STRIDE + 4 + 4 * sc16;
-        *(f32x4*)dst = *(const f32x4*)src;
-        *(f32x4*)(dst + 32 * INP_STRIDE) = *(const f32x4*)(src + 32 * 64);
+        const f32x4 c0 = *(const f32x4*)src, c1 = *(const f32x4*)(src + 32 * 64);
+        *(f32x4*)dst = c0;
+        *(f32x4*)(dst + 32 * INP_STRIDE) = c1;
+        if constexpr (C2H) {
+            const unsigned int mx = c12_rowmax(c12_absmax8(c0, c1));
+            if ((lane & 15) == 0) atomicMax((unsigned int*)(smem + OFF_XMAX), mx);
+        }
     }
     __syncthreads();
+    // C2H: the scale of this cell's V (a wave-uniform power of two, kept in scalar registers) and what undoes it and the weights'
+    float vscale = 1.0f, vunscale = 1.0f;
+    auto set_scale = [&]() {
+        const float xm = __builtin_bit_cast(float, *(const unsigned int*)(smem + OFF_XMAX));
+        const float vb = 100.0f * fmaf(p1a, xm, p1b);                       // >= every |V| of the cell
+        int E = (int)((__builtin_bit_cast(unsigned int, vb) >> 23) & 0xffu);
+        E = E < 40 ? 40 : (E > 254 ? 254 : E);
+        E = __builtin_amdgcn_readfirstlane(E);
+        vscale = __builtin_bit_cast(float, (unsigned int)(268 - E) << 23);      // puts vb into [2^14, 2^15)
+        vunscale = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23) * inv_sw;
+    };
+    if constexpr (C2H) set_scale();
     // records of group gn's crop rows (INP rows row0 .. row0 + rows - 1: conv rows 16 gn + 2 .. 16 gn + 17 and their halo; group 0
     // also conv rows 0, 1; the last group stops at the bottom halo row)
     auto build_records = [&](int gn, int t) {
@@ -212,6 +270,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             asm volatile("" : "+v"(t2));
             const int l2 = t2 & 63, li2 = l2 & 15, kq2 = l2 >> 4;
             if constexpr (DIAG) dt = c12_stamp();
+            if constexpr (C2H) {
+                if (g == 1 && t2 == 0) *(unsigned int*)(smem + OFF_XMAX) = 0;   // last read (set_scale) several barriers ago, next atomics in g = 3
+            }
             // ================= P1: the group's new p1 rows (ring positions q; p1 row y = q - 1; q = 0, 33: zero rows)
             f32x4 stg0 = {0.0f, 0.0f, 0.0f, 0.0f}, stg1 = stg0;
             if (g == 3 && has_next) {   // next cell's crop: in flight during this phase, written to LDS in P2
@@ -229,7 +290,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 const bf16x8 Bx3 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 2) * 64 + l2) * 16);
                 const int c1 = s1 * 16 + li2;
                 const float w9 = *(const float*)(smem + OFF_W9 + c1 * 4);
-                const f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);           // bias, bn scale, bn shift, sign
+                f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);                 // bias, bn scale, bn shift, sign
+                if constexpr (C2H) { e1v[1] *= vscale; e1v[2] *= vscale; }              // the ring holds S p1 (exact: S is a power of two)
                 const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
                 // tap (2,2) of the lane's four pixels 4 kq + r (D layout): crop floats (row + 2, 16 xt + 4 kq + r + 5)
                 const int off9 = 2 * INP_STRIDE + 16 * xt + 4 * kq2 + 5;
@@ -299,7 +361,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     B1[s] = *(const float*)(smem + OFF_B1 + ((s1 * 3 + s) * 64 + l2) * 4);
                 }
                 const int c1 = s1 * 16 + li2;
-                const f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);           // bias, bn scale, bn shift, sign
+                f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);                 // bias, bn scale, bn shift, sign
+                if constexpr (C2H) { e1v[1] *= vscale; e1v[2] *= vscale; }
                 // pooled outputs of this lane: ring columns 8 xt + 2 kq + {0,1} (+1: halo), channel c1
                 const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
                 // One row: conv rows 2y, 2y+1 (y = q - 1) of this wave's 16 pixels x 16 channels -> two pooled values per lane.
@@ -381,6 +444,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     float* dst = inp + ((t2 >> 4) + 1) * INP_STRIDE + 4 + 4 * (t2 & 15);
                     *(f32x4*)dst = stg0;
                     *(f32x4*)(dst + 32 * INP_STRIDE) = stg1;
+                    if constexpr (C2H) {
+                        const unsigned int mx = c12_rowmax(c12_absmax8(stg0, stg1));
+                        if ((l2 & 15) == 0) atomicMax((unsigned int*)(smem + OFF_XMAX), mx);
+                    }
                 }
                 // rows first (B^T d), then columns ((B^T d) B): V[r][c]
                 float t[6][6];
@@ -393,12 +460,37 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 #pragma unroll
                     for (int i = 0; i < 6; ++i) t[i][j] = o[i];
                 }
+                if constexpr (C2H) {
+                    // [point][tile][slot ^ ((tile >> 1) & 7)][16 B]: this thread's dword = channel pair ch >> 1 of plane ch & 1
+                    const int pl = ch & 1, pair = ch >> 1;
+                    const int hoff = (tile * 8 + ((pl * 4 + (pair >> 2)) ^ ((tile >> 1) & 7))) * 16 + (pair & 3) * 4;
+                    const unsigned int sel = pl ? 0x03020706u : 0x05040100u;    // odd lane: [lo c-1 | lo c], even lane: [hi c | hi c+1]
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    float o[6];
-                    bt6(t[r], o);
+                    for (int r = 0; r < 6; ++r) {
+                        float o[6];
+                        bt6(t[r], o);
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) *(float*)(smem + (r * 6 + c) * 2048 + voff) = o[c];
+                        for (int c = 0; c < 6; ++c) {
+                            float v = o[c];
+                            // v is the fp32 result of the transform's last fma.  Left visible, the compiler folds that fma into the
+                            // conversion below (v_fma_mixlo_f16: ONE rounding of the exact sum to fp16) while the pack further
+                            // down converts the fp32-rounded v: two different hi values whenever the double rounding matters,
+                            // i.e. a residual taken against the wrong hi -- measured as 2^-10 errors in p2.  Laundered, both are fp16(v).
+                            asm volatile("" : "+v"(v));
+                            const float rr = v - (float)(_Float16)v;                                        // exact in fp32
+                            const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v, rr}, f16x2));   // [hi | lo]
+                            const unsigned int ot = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)pk, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+                            *(unsigned int*)(smem + (r * 6 + c) * 2048 + hoff) = __builtin_amdgcn_perm(ot, pk, sel);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        float o[6];
+                        bt6(t[r], o);
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) *(float*)(smem + (r * 6 + c) * 2048 + voff) = o[c];
+                    }
                 }
             }
             C12_STAMP(2)
@@ -416,7 +508,28 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 char* const e2 = smem + OFF_E2 + w * 2048 + l2 * 16;
                 // three rows of one column: 6 LDS reads, then 24 MFMAs as three interleaved accumulation chains (an MFMA of a
                 // chain issues 3 x 32 cycles after its predecessor, past the matrix pipe's result latency)
+                // C2H: lane (tile li, kq): slots kq (hi) and 4 + kq (lo) of its tile, XORed as in P2
+                const int hoffh = (li2 * 8 + (kq2 ^ ((li2 >> 1) & 7))) * 16;
+                const int hoffl = (li2 * 8 + ((4 + kq2) ^ ((li2 >> 1) & 7))) * 16;
                 auto trio = [&](int cc, int r0, f32x4 (&m)[3]) {
+                    if constexpr (C2H) {
+                        f16x8 ah[3], al[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            const int xi = (r0 + t) * 6 + 3 * gcol + cc;
+                            ah[t] = *(const f16x8*)(smem + xi * 2048 + hoffh);
+                            al[t] = *(const f16x8*)(smem + xi * 2048 + hoffl);
+                        }
+                        auto Uh = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8], U[pt * 8 + 1], U[pt * 8 + 2], U[pt * 8 + 3]}); };
+                        auto Ul = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8 + 4], U[pt * 8 + 5], U[pt * 8 + 6], U[pt * 8 + 7]}); };
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], Ul(cc * 6 + r0 + t), f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], Uh(cc * 6 + r0 + t), m[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], Uh(cc * 6 + r0 + t), m[t], 0, 0, 0);
+                        return;
+                    }
                     f32x4 a[3][2];
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -468,7 +581,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 const char* const e1 = (const char*)(ring + pslot * RING_ROWF + 32) + l2 * 16;
                 const char* const e2 = smem + OFF_E2 + wp * 2048 + l2 * 16;
                 const int co = sl * 16 + li2;
-                const f32x4 e2v = *(const f32x4*)(smem + OFF_EP2 + co * 16);          // bias, bn scale, bn shift, sign
+                f32x4 e2v = *(const f32x4*)(smem + OFF_EP2 + co * 16);                // bias, bn scale, bn shift, sign
+                if constexpr (C2H) e2v[3] *= vunscale;                                // the sums carry S S_w: undone in pool_post's fma
                 // register r <-> tile 4 kq + r of the group (tile row kq >> 1, tile columns 4 (kq & 1) + r); output rows
                 // (2 gcol, 2 gcol + 1) of a tile are pool row gcol: one base address per lane, the rest immediates
                 float* const obase = p2 + ((((size_t)cell * 16 + 2 * (2 * g + (kq2 >> 1)) + gcol) * 16 + 8 * (kq2 & 1)) * 64 + co);
@@ -498,6 +612,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 else finish(std::false_type{});
                 if constexpr (C1X3) {      // V is dead until the next P2: the next group's records (g = 3: the next cell's crop is in place since P2)
                     if (g < 3 || has_next) build_records(g < 3 ? g + 1 : 0, t2);
+                }
+                if constexpr (C2H) {
+                    if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2
                 }
             }
             C12_STAMP(6)
@@ -540,6 +657,60 @@ size_t pack_conv12_fragments(const float* hwio /* [3][3][32][64] */, const float
                     }
     }
     return total;
+}
+
+// The same U for the fp16 form of P3 (C2H): two fp16 planes of S_w U, S_w the power of two that puts max|U| into [2^14, 2^15).
+// dst[wave w][(cc * 6 + r) * 8 + plane * 4 + d][lane] = the dword {ci = 8 kq + 2 d (low half), ci + 1 (high half)} of that plane of
+// U[row r][col 3 gcol + cc][ci][co = 16 sl + li]; *inv_sw = 1 / S_w.  Returns 32-bit words.
+size_t pack_conv12_fragments_h2(const float* hwio /* [3][3][32][64] */, const float* bn_scale /* [64] */, unsigned int* dst, float* inv_sw)
+{
+    const size_t total = (size_t)8 * 144 * 64;
+    if (!dst) return total;
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    std::vector<float> U((size_t)36 * 32 * 64);
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c)
+            for (int ci = 0; ci < 32; ++ci)
+                for (int co = 0; co < 64; ++co) {
+                    double u = 0.0;
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) u += G[r][a] * (double)hwio[((size_t)(a * 3 + b) * 32 + ci) * 64 + co] * G[c][b];
+                    if (bn_scale[co] < 0.0f) u = -u;          // the kernel pools -z for these filters (pool_post)
+                    U[((size_t)(r * 6 + c) * 32 + ci) * 64 + co] = (float)u;
+                }
+    const float S = f16x2_weight_scale(U.data(), U.size());
+    if (inv_sw) *inv_sw = 1.0f / S;
+    for (int w = 0; w < 8; ++w) {
+        const int gcol = w & 1, sl = w >> 1;
+        for (int cc = 0; cc < 3; ++cc)
+            for (int r = 0; r < 6; ++r)
+                for (int pl = 0; pl < 2; ++pl)
+                    for (int d = 0; d < 4; ++d)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int li = lane & 15, kq = lane >> 4, co = 16 * sl + li, c = 3 * gcol + cc;
+                            uint16_t h[2][2];
+                            for (int e = 0; e < 2; ++e)
+                                f16x2_split(U[((size_t)(r * 6 + c) * 32 + 8 * kq + 2 * d + e) * 64 + co], S, h[e][0], h[e][1]);
+                            dst[((size_t)w * 144 + (cc * 6 + r) * 8 + pl * 4 + d) * 64 + lane] = (unsigned int)h[0][pl] | ((unsigned int)h[1][pl] << 16);
+                        }
+    }
+    return total;
+}
+
+// max|p1| <= a1 max|x| + b1 for every crop: |p1_c| = |s_c relu(w_c . x + b_c) + t_c| <= |s_c| (||w_c||_1 max|x| + max(b_c, 0)) + |t_c|
+void pack_conv12_p1_bound(const float* hwio /* [3][3][1][32] */, const float* ep1 /* [3][32]: bias, bn scale, bn shift */, float* a1, float* b1)
+{
+    float a = 0.0f, b = 0.0f;
+    for (int co = 0; co < 32; ++co) {
+        float l1 = 0.0f;
+        for (int t = 0; t < 9; ++t) l1 += fabsf(hwio[(size_t)t * 32 + co]);
+        const float sc = fabsf(ep1[32 + co]);
+        a = fmaxf(a, sc * l1);
+        b = fmaxf(b, sc * fmaxf(ep1[co], 0.0f) + fabsf(ep1[64 + co]));
+    }
+    *a1 = a * 1.0001f;       // the sums above are rounded: keep the bound a bound
+    *b1 = b * 1.0001f + 1e-30f;
 }
 
 // conv1's B fragments for the fused kernel: pack_conv_fragments(cin = 1) layout [slice][K step][lane] with the kernels of
@@ -603,15 +774,17 @@ unsigned long long* g_c12_diag = nullptr;
 int g_c12_diag_blocks = 0;
 
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3)
+                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3, const unsigned int* ufrag_h2, float p1a, float p1b,
+                               float inv_sw)
 {
     static int cus = 0;
     static const bool diag = getenv("CS_C12_DIAG") != nullptr;
     if (!cus) {
         hipError_t e;
-#define C12_ATTR(D, X)                                                                                                              \
-    if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<D, X>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
-        C12_ATTR(false, false); C12_ATTR(true, false); C12_ATTR(false, true); C12_ATTR(true, true);
+#define C12_ATTR(D, X, H)                                                                                                           \
+    if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<D, X, H>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
+        C12_ATTR(false, false, false); C12_ATTR(true, false, false); C12_ATTR(false, true, false); C12_ATTR(true, true, false);
+        C12_ATTR(false, true, true); C12_ATTR(true, true, true);
 #undef C12_ATTR
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
@@ -625,11 +798,12 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
     if (n_cells <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);      // one workgroup per CU (LDS-bound), persistent over cells
     unsigned long long* const dp = diag ? g_c12_diag : nullptr;
-#define C12_GO(D, X)                                                                                                                \
-    hipLaunchKernelGGL((conv12_fused_kernel<D, X>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, ufrag, ep2, p2,       \
-                       (long)n_cells, dp, w1x3)
-    if (w1x3) { if (diag) C12_GO(true, true); else C12_GO(false, true); }       // conv1 on bf16 MFMAs
-    else      { if (diag) C12_GO(true, false); else C12_GO(false, false); }
+#define C12_GO(D, X, H, UF)                                                                                                         \
+    hipLaunchKernelGGL((conv12_fused_kernel<D, X, H>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, UF, ep2, p2,      \
+                       (long)n_cells, dp, w1x3, p1a, p1b, inv_sw)
+    if (w1x3 && ufrag_h2) { if (diag) C12_GO(true, true, true, (const float*)ufrag_h2); else C12_GO(false, true, true, (const float*)ufrag_h2); }   // conv2 as an fp16 split
+    else if (w1x3) { if (diag) C12_GO(true, true, false, ufrag); else C12_GO(false, true, false, ufrag); }       // conv1 on bf16 MFMAs
+    else           { if (diag) C12_GO(true, false, false, ufrag); else C12_GO(false, false, false, ufrag); }
 #undef C12_GO
     return hipGetLastError();
 }

@@ -23,6 +23,7 @@
 // transform, so only nine accumulators are live at a time.
 #include "common.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -749,6 +750,323 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same kernel with conv6's contraction as a TWO-term fp16 split (three products) instead of the three-term bf16 split
+// (six): fp16 carries 11 significant bits, so x = hi + lo (hi = fp16(x), lo = fp16(x - hi)) holds 22, and
+//     x w ~ hi_x hi_w + (hi_x lo_w + lo_x hi_w)
+// with every partial product exact in the MFMA's fp32 accumulator (v_mfma_f32_16x16x32_f16, the bf16 instruction's rate): HALF
+// the matrix instructions, two thirds of the weight registers and LDS bytes, a 3-instruction split per value instead of 5.5.
+// What it needs that bf16 does not is range (fp16: 2^-14 .. 65504): operands carry exact power-of-two scales.
+//   weights   S_w = the power of two that puts max|W_eff| in [2^14, 2^15), applied on the host (pack_conv6_f16x2);
+//   a5        a scale per staged STRIP (6 stored rows): S_a puts the strip's max|a5| in [2^14, 2^15).  The max is taken where
+//             the strip is staged (registers -> DPP row max -> one LDS atomic max per 16 lanes, read back after the barrier that
+//             is there anyway), so it depends on the cell's own data only: results do not depend on what else is in the batch;
+//   undo      acc * 2^-(e_a + e_w) in the epilogue's fma (exact: a power of two).
+// With the scale this tight the residuals need no scale of their own: lo is a normal fp16 for every |x| above 2^-18 of the
+// strip's maximum and loses at most 2^-40 of that maximum below (MI355X: the f16 MFMA takes subnormal inputs as they are and
+// its products are exact -- tools/microbench/fp16_mfma_probe.hip, profiles/r03_fp16_mfma_probe.json).  One MFMA carries ONE
+// magnitude (hi hi | hi lo, lo hi on a second accumulator), as in the bf16 kernels.  Error against the fp64 oracle:
+// tests/study_split_fp16.py (CPU emulation: a6 1.8e-7 of its range; the fp32 MFMA chain 7.2e-7) and the unchanged -m gpu bars.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct F67H {
+    static constexpr int PLB = 2 * 64;                         // bytes of one plane of a pixel: 64 channels
+    static constexpr int PXB = 2 * PLB + 32;                   // 288 B per staged pixel = twice an odd number of 16-byte slots
+    static constexpr int ROWB = 18 * PXB;
+    static constexpr int STRIP = 6 * ROWB;                     // 31,104 B
+    static constexpr int TW = F67X::TW;
+    static constexpr int T_BYTES = F67X::T_BYTES;
+    static constexpr int OFF_MAX = STRIP + F67::A6_BYTES + T_BYTES + F67::W_BYTES;   // two words: the strip maxima (alternating)
+    static constexpr int LDS = OFF_MAX + 16;
+    static_assert(LDS <= 160 * 1024 && STRIP % 16 == 0, "LDS budget");
+};
+
+// max|v| over the 16 lanes of a DPP row (quad swaps, then row rotations by 4 and 8)
+__device__ __forceinline__ unsigned int h2_rowmax(unsigned int m)
+{
+    unsigned int o;
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [1,0,3,2]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [2,3,0,1]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:4
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:8
+    return m;
+}
+
+// the power of two S that puts a maximum with float bits `mbits` (>= 0) into [2^14, 2^15), and 1 / S.  The exponent is clamped
+// so that both stay normal floats: a strip whose maximum is below 2^-87 (or zero) is scaled by 2^101 -- its values then sit in
+// fp16's lowest binades or vanish, 2^-87 of anything the next layer can see.
+__device__ __forceinline__ void h2_scale(unsigned int mbits, float& S, float& invS)
+{
+    int E = (int)((mbits >> 23) & 0xffu);
+    E = E < 40 ? 40 : (E > 254 ? 254 : E);
+    S = __builtin_bit_cast(float, (unsigned int)(268 - E) << 23);          // 2^(14 - (E - 127))
+    invS = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23);
+}
+
+__device__ __forceinline__ void h2_split4(const f32x4& x, float S, f16x4& hi, f16x4& lo)
+{
+    const f32x4 v = x * S;
+    hi = __builtin_convertvector(v, f16x4);
+    const f32x4 r = v - __builtin_convertvector(hi, f32x4);            // exact in fp32
+    lo = __builtin_convertvector(r, f16x4);
+}
+
+__device__ __forceinline__ void h2_store(char* strip, int j, int rsub, int loffb, const f32x4& v, float S)
+{
+    const int r = rsub + WUL6::RPP * j;
+    f16x4 hi, lo;
+    h2_split4(v, S, hi, lo);
+    char* d = strip + r * F67H::ROWB + loffb;
+    *(f16x4*)d = hi;
+    *(f16x4*)(d + F67H::PLB) = lo;
+}
+
+// the staged value of pass j (zero for the halo rows of the image) and its contribution to the strip's max|.|
+__device__ __forceinline__ f32x4 h2_prep(int y0, int j, int rsub, f32x4 v, unsigned int& mx)
+{
+    const int sy = y0 - 1 + rsub + WUL6::RPP * j;
+    if (sy < 0 || sy >= WUL6::HS) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 whatever the index -- clang 19, ROCm 7.2)
+    const float a = v[0], b = v[1], c = v[2], d = v[3];
+    const unsigned int u = __builtin_bit_cast(unsigned int, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
+    mx = mx > u ? mx : u;
+    return v;
+}
+
+// DIAG stamps as conv67_x3_kernel's.
+template <bool DIAG>
+__global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
+    const float* __restrict__ in /* a5 */, const f16x8* __restrict__ wfrag, const float* __restrict__ ep /* [3][32] */,
+    const float* __restrict__ x /* crops [n][64][64] */, const float* __restrict__ weff /* [16][32] */,
+    const float* __restrict__ b7p, float* __restrict__ errpart /* [n][8][2] */, long n_cells, float inv_sw,
+    unsigned long long* __restrict__ diag)
+{
+    using C = WUL6;
+    static_assert(C::NLD == 3 && C::RPP == 2 && C::R == 6 && C::EPR == 256, "row-wise staging constants");
+    unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* a6s = (float*)(smem + F67H::STRIP);
+    float* tb = (float*)(smem + F67H::STRIP + F67::A6_BYTES);
+    float* wl = (float*)(smem + F67H::STRIP + F67::A6_BYTES + F67H::T_BYTES);
+    unsigned int* mxw = (unsigned int*)(smem + F67H::OFF_MAX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave >> 1, wsl = wave & 1;
+    const int pa = ph >> 1, pb = ph & 1;
+    const int li = lane & 15, kq = lane >> 4;
+
+    f16x8 B[4][2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) B[t][k][p] = wfrag[(((wave * 4 + t) * 2 + k) * 2 + p) * 64 + lane];
+    const int co = wsl * 16 + li;
+    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+    const float b7 = b7p[0];
+
+    const long first = blockIdx.x;
+    if (first >= n_cells) return;
+    const int se = tid & (C::EPR - 1), rsub = tid / C::EPR;
+    const int spx = se / C::C4, sc4 = se & (C::C4 - 1);
+    const int goff = spx * C::CIN + sc4 * 4;
+    const int loffb = (spx + 1) * F67H::PXB + sc4 * 8;             // +1: halo column (zeroed once, never rewritten)
+    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::HS * C::WS * C::CIN; };
+    for (int i = tid; i < F67H::LDS / 16; i += C::THREADS) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    wl[(tid >> 5) * 36 + (tid & 31)] = weff[tid];                  // [n][c], 512 floats, padded rows
+    float unscale;                                                 // 1 / (S_a S_w) of the strip the MFMAs read
+    {
+        f32x4 stg[C::NLD];
+        unsigned int mx = 0;
+#pragma unroll
+        for (int j = 0; j < C::NLD; ++j) stg[j] = h2_prep(0, j, rsub, wu_load<C>(cell_ptr(first), 0, j, rsub, goff), mx);
+        mx = h2_rowmax(mx);
+        if (li == 0) atomicMax(&mxw[0], mx);
+        __syncthreads();
+        float S, invS;
+        h2_scale(mxw[0], S, invS);
+        unscale = invS * inv_sw;
+#pragma unroll
+        for (int j = 0; j < C::NLD; ++j) h2_store(smem, j, rsub, loffb, stg[j], S);
+    }
+    __syncthreads();
+    if (tid == 0) mxw[0] = 0;                                      // the next use of word 0 is two strips away, behind barriers
+    // A operand: stored (t + a - 1 + ry, xs + b - 1 + rx) of the group = staged (t + a + ry, xs + b + rx); lane = (xs, 8 channels at 8 kq)
+    const char* abase = smem + (pa * 18 + li + pb) * F67H::PXB + kq * 16;
+
+    int strip_no = 0;                                              // strips staged so far by this workgroup: word (strip_no & 1) collects the next maximum
+    for (long cell = first; cell < n_cells; cell += gridDim.x) {
+        const float* xc = x + (size_t)cell * 64 * 64;
+        float s2 = 0.0f, s1 = 0.0f;
+#pragma unroll 1
+        for (int grp = 0; grp < C::NGRP; ++grp) {
+            const long ncell = grp < C::NGRP - 1 ? cell : cell + gridDim.x;
+            const int ngrp = grp < C::NGRP - 1 ? grp + 1 : 0;
+            const bool has_next = ncell < n_cells;
+            ++strip_no;
+            unsigned int* const mword = mxw + (strip_no & 1);
+
+            if constexpr (DIAG) dt = wu_stamp();
+            f32x4 stg[C::NLD];
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(cell_ptr(ncell), ngrp * C::SR, j, rsub, goff);
+            }
+            // the crop pixels this thread's outputs are compared with (unconditional, clamped loads)
+            float xv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = wave + 8 * h, o = 2 * (8 * grp + (k >> 1)) - 1 + (k & 1);
+                xv[h] = xc[(o < 0 ? 0 : o) * 64 + lane];
+            }
+            float xtail = 0.0f;
+            if (grp == C::NGRP - 1 && wave == 0) xtail = xc[63 * 64 + lane];
+
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[0] += t - dt; dt = t; }
+            // ---- conv6, folded direct, three fp16 products per (tile, tap, 32-channel block); the large products and the two
+            // cross terms on separate accumulators
+            f32x4 ah[4], al[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ah[t] = al[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // walked by STAGED fragment as in conv67_x3_kernel: the fragment at staged row sr (column shift rx, block k) is tap
+            // (0, rx) of tile sr and tap (1, rx) of tile sr - 1
+            auto rd = [&](int f, f16x8 (&a)[2]) {
+                const int sr = f >> 2, rx = (f >> 1) & 1, k = f & 1;
+                const char* p = abase + sr * F67H::ROWB + rx * F67H::PXB + k * 64;
+                a[0] = *(const f16x8*)p;
+                a[1] = *(const f16x8*)(p + F67H::PLB);
+            };
+            auto mac3 = [&](const f16x8 (&a)[2], const f16x8 (&b)[2], f32x4& dh, f32x4& dl) {
+                dl = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], dl, 0, 0, 0);
+                dh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], dh, 0, 0, 0);
+                dl = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], dl, 0, 0, 0);
+            };
+            {
+                f16x8 a[2];
+                rd(0, a);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int f = 0; f < 20; ++f) {
+                    const int sr = f >> 2, rx = (f >> 1) & 1, k = f & 1;
+                    f16x8 an[2] = {a[0], a[1]};
+                    if (f + 1 < 20) rd(f + 1, an);
+                    if (sr < 4) mac3(a, B[rx][k], ah[sr], al[sr]);
+                    if (sr > 0) mac3(a, B[2 + rx][k], ah[sr - 1], al[sr - 1]);
+                    a[0] = an[0]; a[1] = an[1];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (sr > 0 && sr < 4) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+            }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(ah[0][0]), "v"(al[3][3]));
+                const unsigned long long t = wu_stamp(); dg[1] += t - dt; dt = t;
+            }
+            // ---- undo the scales, bias -> relu -> BN; D row 4 kq + r = stored pixel xs of stored row t -> a6 block row 2 t + a, column 2 xs + b
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(fmaf(ah[t][r] + al[t][r], unscale, bias), 0.0f);
+                    a6s[((2 * t + pa) * 32 + 2 * (4 * kq + r) + pb) * F67::PA + co] = fmaf(v, bns, bnt);
+                }
+            // the next strip's values are here by now (loaded at the top of the group): its max|.| into this strip's word
+            if (has_next) {
+                unsigned int mx = 0;
+#pragma unroll
+                for (int j = 0; j < C::NLD; ++j) stg[j] = h2_prep(ngrp * C::SR, j, rsub, stg[j], mx);
+                mx = h2_rowmax(mx);
+                if (li == 0) atomicMax(mword, mx);
+            }
+            __syncthreads();
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[2] += t - dt; dt = t; }
+            // ---- T = a6 W_eff^T for local row `wave`, 16 pixels per MFMA chain; K order: channel 8 kq + s
+            float wc[8];                                                                 // W_eff[n = li][c = 8 kq + s]
+            *(f32x4*)&wc[0] = *(const f32x4*)(wl + li * 36 + kq * 8);
+            *(f32x4*)&wc[4] = *(const f32x4*)(wl + li * 36 + kq * 8 + 4);
+            {
+                const float* ap = a6s + ((wave * 32 + li) * F67::PA + kq * 8);
+                const f32x4 a00 = *(const f32x4*)ap, a01 = *(const f32x4*)(ap + 4);
+                const f32x4 a10 = *(const f32x4*)(ap + 16 * F67::PA), a11 = *(const f32x4*)(ap + 16 * F67::PA + 4);
+                f32x4 t0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;                     // two independent chains, interleaved
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[s], wc[s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[s], wc[s], t1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
+                }
+                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67H::TW + 4 * kq + 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { tw[r] = t0[r]; tw[16 + r] = t1[r]; }
+            }
+            if (has_next) {      // every wave is past the first barrier: nobody reads the current strip any more, and the word holds the maximum
+                float S, invS;
+                h2_scale(*mword, S, invS);
+                unscale = invS * inv_sw;
+#pragma unroll
+                for (int j = 0; j < C::NLD; ++j) h2_store(smem, j, rsub, loffb, stg[j], S);
+            }
+            __syncthreads();
+            if (tid == 0) *mword = 0;            // read by everyone before the barrier above; its next atomics come two groups later
+            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
+            // ---- gather: new a6 row y finishes output rows 2y - 1 (phase a = 1 of row y - 1) and 2y (a = 0)
+            const int px = lane & 1, xh = (lane >> 1) + px;                              // halo column of rx = 0
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = wave + 8 * h;                                              // wave-uniform
+                const int y = 8 * grp + (k >> 1), e = k & 1;
+                if (2 * y - 1 + e < 0) continue;
+                const int nb = ((1 - e) * 2 + px) * 4;
+                const float* ra = tb + ((((y - 1) & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
+                const float* rb = tb + (((y & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
+                float ta0 = ra[0], ta1 = ra[F67H::TW + 1];
+                const float tb0 = rb[2 * F67H::TW], tb1 = rb[3 * F67H::TW + 1];
+                if (y == 0) { ta0 = 0.0f; ta1 = 0.0f; }                                  // row -1: zero padding
+                const float v = ((ta0 + ta1) + (tb0 + tb1)) + b7;
+                const float rr = f67_sigmoid(v);
+                const float d = xv[h] - rr;
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+            }
+            if (grp == C::NGRP - 1 && wave == 0) {                                      // output row 63: a6 row 31 and the padding
+                const int nb = (2 + px) * 4;
+                const float* ra = tb + (((31 & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
+                const float v = (ra[0] + ra[F67H::TW + 1]) + b7;
+                const float rr = f67_sigmoid(v);
+                const float d = xtail - rr;
+                s2 = fmaf(d, d, s2);
+                s1 += fabsf(d);
+            }
+            if constexpr (DIAG) {
+                asm volatile("" ::"v"(s2), "v"(s1));
+                const unsigned long long t = wu_stamp(); dg[4] += t - dt; dt = t;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_down(s2, off, 64);
+            s1 += __shfl_down(s1, off, 64);
+        }
+        if (lane == 0) {
+            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 0] = s2;
+            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 1] = s1;
+        }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) diag[((size_t)blockIdx.x * 8 + wave) * 5 + k] = dg[k];
+        }
+    }
+}
+
 // U = G W_eff G^T per (phase, cin, cout), evaluated in double and rounded once.
 // Layout [wave = phase * 2 + half][(k * 9 + xi) * KS + 4 q + j][lane]:
 //   U[xi = 3 r + c][ci = 16 q + 4 kq + j][co = 16 (half * NSW + k) + li].
@@ -914,6 +1232,79 @@ hipError_t launch_conv67_x3(const float* a5, const uint16_t* wplanes, const floa
     else
         hipLaunchKernelGGL(conv67_x3_kernel<false>, dim3(grid), dim3(WUL6::THREADS), F67X::LDS, stream, a5, (const bf16x8*)wplanes, ep, x,
                            weff_dev, b7_dev, errpart, (long)n_cells, (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
+
+// The power of two that puts max|w| into [2^14, 2^15) (1 for an all-zero array), for the fp16 split of a weight array.
+float f16x2_weight_scale(const float* w, size_t n)
+{
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(w[i]));
+    if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
+    int e;
+    frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 15 - e);         // S m = f 2^15 in [2^14, 2^15)
+}
+
+// one value -> its two fp16 terms (bit patterns): hi = fp16(S w), lo = fp16(S w - hi)
+void f16x2_split(float w, float S, uint16_t& hi, uint16_t& lo)
+{
+    const float v = w * S;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    memcpy(&hi, &h, 2);
+    memcpy(&lo, &l, 2);
+}
+
+// conv6's folded weights (pack_generic_folded(64, 32, ...): [phase 4][tap 4][cin 64][cout 32]) as two fp16 planes in conv67_h2_kernel's
+// order: [wave = phase * 2 + half][tap][block 2][plane 2][lane 64][8]: element j = plane of S_w W_eff[phase][tap][32 block + 8 kq + j][16 half + li];
+// *inv_sw = 1 / S_w
+size_t pack_conv6_f16x2(const float* weff, uint16_t* dst, float* inv_sw)
+{
+    const size_t n = (size_t)8 * 4 * 2 * 2 * 64 * 8;
+    if (!dst) return n;
+    const float S = f16x2_weight_scale(weff, (size_t)16 * 64 * 32);
+    if (inv_sw) *inv_sw = 1.0f / S;
+    for (int w = 0; w < 8; ++w)
+        for (int t = 0; t < 4; ++t)
+            for (int k = 0; k < 2; ++k)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ph = w >> 1, half = w & 1, li = l & 15, kq = l >> 4;
+                        const float v = weff[((size_t)(ph * 4 + t) * 64 + 32 * k + 8 * kq + j) * 32 + 16 * half + li];
+                        uint16_t pl[2];
+                        f16x2_split(v, S, pl[0], pl[1]);
+                        for (int p = 0; p < 2; ++p) dst[((((((size_t)w * 4 + t) * 2 + k) * 2 + p) * 64) + l) * 8 + j] = pl[p];
+                    }
+    return n;
+}
+
+hipError_t launch_conv67_h2(const float* a5, const uint16_t* wplanes, float inv_sw, const float* ep, const float* x, const float* weff_dev,
+                            const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream)
+{
+    static int cus = 0;
+    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
+    if (!cus) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv67_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F67H::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv67_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F67H::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (diag && !g_wu_diag[3]) {                               // slot 3 of the diagnostic table: the fused kernel (any form)
+            if ((e = hipMalloc(&g_wu_diag[3], (size_t)cus * 40 * sizeof(unsigned long long))) != hipSuccess) return e;
+            g_wu_diag_blocks[3] = cus;
+        }
+    }
+    if (n_cells <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);
+    if (diag)
+        hipLaunchKernelGGL(conv67_h2_kernel<true>, dim3(grid), dim3(WUL6::THREADS), F67H::LDS, stream, a5, (const f16x8*)wplanes, ep, x,
+                           weff_dev, b7_dev, errpart, (long)n_cells, inv_sw, g_wu_diag[3]);
+    else
+        hipLaunchKernelGGL(conv67_h2_kernel<false>, dim3(grid), dim3(WUL6::THREADS), F67H::LDS, stream, a5, (const f16x8*)wplanes, ep, x,
+                           weff_dev, b7_dev, errpart, (long)n_cells, inv_sw, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 

@@ -105,6 +105,34 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_stats_final_kernel(const float
     }
 }
 
+// The same merge, leaving the merged {count, mean, M2} of every channel as ONE partial [3][C] (floats, the layout of `part`):
+// a rank's contribution to a synchronised BatchNormalization -- the triples of all ranks are then merged by
+// bn_stats_final_kernel exactly as it merges workgroups' partials.
+__global__ __launch_bounds__(BNF_THREADS) void bn_stats_merge_kernel(const float* __restrict__ part, int G, int C, float* __restrict__ out)
+{
+    __shared__ double sn[BNF_THREADS], smu[BNF_THREADS], sM2[BNF_THREADS];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int g0 = (G * tid) / BNF_THREADS, g1 = (G * (tid + 1)) / BNF_THREADS;
+    ChanStat a{0.0, 0.0, 0.0};
+    for (int g = g0; g < g1; ++g) {
+        const float* o = part + (size_t)g * 3 * C;
+        chan_merge(a, o[c], o[C + c], o[2 * C + c]);
+    }
+    sn[tid] = a.n; smu[tid] = a.mu; sM2[tid] = a.M2;
+    __syncthreads();
+    for (int half = BNF_THREADS / 2; half >= 1; half >>= 1) {
+        ChanStat m{0.0, 0.0, 0.0};
+        if (tid < half) {
+            m = ChanStat{sn[2 * tid], smu[2 * tid], sM2[2 * tid]};
+            chan_merge(m, sn[2 * tid + 1], smu[2 * tid + 1], sM2[2 * tid + 1]);
+        }
+        __syncthreads();
+        if (tid < half) { sn[tid] = m.n; smu[tid] = m.mu; sM2[tid] = m.M2; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[c] = (float)sn[0]; out[C + c] = (float)smu[0]; out[2 * C + c] = (float)sM2[0]; }
+}
+
 // y = gamma*(r-mean)*inv + beta, then 2x2 max-pool (encoder) or identity (decoder).
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const float* __restrict__ r, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -568,13 +596,22 @@ __global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndes
     }
 }
 
-// Keras Adam: w -= alpha * m / (sqrt(v) + eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host.
+// Keras Adam: w -= alpha * m / (sqrt(v) + eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host and passed by value
+// (alpha_dev, when not NULL, overrides it from device memory).  macc (optional): the running sums Keras keeps over an epoch --
+// {sum of batch losses, sum of batch MAEs, batches} in double, advanced by the step's {loss, mae} in batch_scal -- so that an
+// epoch of steps needs no host round trip (cs_train_step_async / cs_train_read_metrics).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, const float* __restrict__ alpha_dev, float b1, float b2, float eps)
+                            float* __restrict__ v, long n, const float* __restrict__ alpha_dev, float alpha_val, float b1, float b2, float eps,
+                            const float* __restrict__ batch_scal, double* __restrict__ macc)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && macc) {
+        macc[0] += (double)batch_scal[0];
+        macc[1] += (double)batch_scal[1];
+        macc[2] += 1.0;
+    }
     if (i >= n) return;
-    const float alpha = *alpha_dev;     // changes every step: read from memory so that the launch itself never does
+    const float alpha = alpha_dev ? *alpha_dev : alpha_val;
     const float gi = g[i];
     const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
     const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
@@ -686,6 +723,12 @@ hipError_t launch_bn_stats_final(const float* part, int G, int C, float eps, flo
     return hipGetLastError();
 }
 
+hipError_t launch_bn_stats_merge(const float* part, int G, int C, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((unsigned)C), dim3(BNF_THREADS), 0, s, part, G, C, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const float* beta, const float* stats, float* a,
                            long N, int H, int W, int pool, hipStream_t s)
 {
@@ -770,9 +813,10 @@ hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_
 }
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, const float* alpha, float b1, float b2, float eps,
-                       hipStream_t s)
+                       hipStream_t s, float alpha_val, const float* batch_scal, double* macc)
 {
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, alpha, b1, b2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, alpha, alpha_val, b1, b2, eps,
+                       batch_scal, macc);
     return hipGetLastError();
 }
 

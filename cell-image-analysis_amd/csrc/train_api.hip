@@ -152,6 +152,12 @@ int cs_train_create(const cs_cae_weights* init, const cs_train_cfg* cfg, int dev
     }
     TFAIL(upload(t->P, hp.data(), o * 4));
     TFAIL(upload(t->MOV, hm.data(), mo * 4));
+    {
+        const double z3[4] = {0.0, 0.0, 0.0, 0.0};
+        TFAIL(upload(t->macc, z3, sizeof z3));
+        hipError_t e = hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming);
+        if (e != hipSuccess) { delete t; return fail(CS_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
     TFAIL(t->Gown.ensure(o * 4)); TFAIL(t->M.ensure(o * 4)); TFAIL(t->V.ensure(o * 4));
     t->G = t->Gown.as<float>();
     {
@@ -215,6 +221,28 @@ int cs_train_set_grad_buffer(cs_trainer* t, float* device_buffer)
     return CS_OK;
 }
 
+int cs_train_set_sync_bn(cs_trainer* t, cs_allgather_fn fn, void* ctx, float* device_buf, int64_t capacity_floats, int rank, int world)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (!fn) { t->sync_fn = nullptr; t->sync_world = 1; t->sync_rank = 0; return CS_OK; }
+    if (!t->ref) return fail(CS_ERR_UNSUPPORTED, "synchronised BatchNormalization is built for the reference graph's trainer");
+    if (!device_buf || world < 1 || rank < 0 || rank >= world || capacity_floats < (int64_t)world * 3 * 64)
+        return fail(CS_ERR_INVALID, "sync buffer NULL / too small (needs world x 192 floats) or bad rank/world");
+    int rc = t->sync_scratch.ensure(2 * 64 * sizeof(float));
+    if (rc) return rc;
+    t->sync_fn = fn; t->sync_ctx = ctx; t->sync_buf = device_buf; t->sync_cap = capacity_floats; t->sync_rank = rank; t->sync_world = world;
+    return CS_OK;
+}
+
+// this rank's values are in its slot of the exchange buffer (enqueued): drain the stream, let the caller all-gather
+static int sync_gather(cs_trainer* t, int64_t floats_per_rank)
+{
+    HIPCHK(hipStreamSynchronize(t->stream));
+    const int rc = t->sync_fn(t->sync_ctx, floats_per_rank);
+    if (rc) return fail(CS_ERR_INVALID, "the all-gather hook of cs_train_set_sync_bn returned %d", rc);
+    return CS_OK;
+}
+
 static int copy_in(cs_trainer* t, DevBuf& dst, const float* src, int kind, size_t floats)
 {
     HIPCHK(hipMemcpyAsync(dst.p, src, floats * 4, kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, t->stream));
@@ -265,6 +293,15 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
         LCHK(launch_conv_train_fwd(l, in, t->wf[l].as<float>(), P + t->off_b[l], t->r[l].as<float>(), B, s));
         int G1 = 0;
         LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * Hc * Hc, C, t->part_stats.as<float>(), &G1, s));
+        if (t->sync_fn) {
+            // the local partials -> ONE {count, mean, M2} triple per channel in this rank's slot, all-gather, and the final merge
+            // runs over the ranks' triples: the statistics (and the moving averages) of the whole batch, identical on every rank
+            LCHK(launch_bn_stats_merge(t->part_stats.as<float>(), G1, C, t->sync_buf + (size_t)t->sync_rank * 3 * C, s));
+            int rc = sync_gather(t, 3 * C);
+            if (rc) return rc;
+            LCHK(launch_bn_stats_final(t->sync_buf, t->sync_world, C, t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l],
+                                       MOV + t->off_mv[l], t->stats[l].as<float>(), s));
+        } else
         LCHK(launch_bn_stats_final(t->part_stats.as<float>(), G1, C, t->cfg.bn_eps, t->cfg.bn_momentum, MOV + t->off_mm[l],
                                    MOV + t->off_mv[l], t->stats[l].as<float>(), s));
         LCHK(launch_bn_apply(t->r[l].as<float>(), C, P + t->off_g[l], P + t->off_be[l], t->stats[l].as<float>(),
@@ -294,6 +331,16 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
         int G2 = 0;
         LCHK(launch_bn_bwd_reduce(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
                                   P + t->off_be[l], B, Hc, Hc, C, pool, t->part_bwd.as<float>(), &G2, s));
+        if (t->sync_fn) {
+            // dgamma / dbeta stay this rank's share (the gradient all-reduce averages them like every other gradient); the two
+            // MEANS that dz needs are those of the whole batch: raw local sums -> slot, all-gather, summed in rank order
+            LCHK(launch_bn_bwd_final(t->part_bwd.as<float>(), G2, C, 1.0, t->sync_buf + (size_t)t->sync_rank * 2 * C,
+                                     G + t->off_g[l], G + t->off_be[l], s));
+            int rc = sync_gather(t, 2 * C);
+            if (rc) return rc;
+            LCHK(launch_bn_bwd_final(t->sync_buf, t->sync_world, C, (double)B * t->sync_world * Hc * Hc, t->bwd_sums.as<float>(),
+                                     t->sync_scratch.as<float>(), t->sync_scratch.as<float>() + 64, s));
+        } else
         LCHK(launch_bn_bwd_final(t->part_bwd.as<float>(), G2, C, (double)B * Hc * Hc, t->bwd_sums.as<float>(),
                                  G + t->off_g[l], G + t->off_be[l], s));
         LCHK(launch_bn_bwd_dz(t->da[l].as<float>(), t->r[l].as<float>(), t->stats[l].as<float>(), P + t->off_g[l],
@@ -371,6 +418,68 @@ int cs_train_step(cs_trainer* t, const float* x, const float* y, int64_t batch, 
     return CS_OK;
 }
 
+// One fit() batch with NO host synchronisation: input copies, forward, backward, Adam and the re-pack are enqueued on the
+// handle's stream and the call returns.  The batch's loss / MAE are added to running sums on the device (what Keras shows as
+// an epoch's loss: the mean over its batches); cs_train_read_metrics fetches them with one round trip per epoch.  x and y must
+// stay valid until the step's input copies have run: cs_train_inputs_consumed makes a stream of the caller's wait for exactly that
+// (the Python wrapper does it with torch's current stream, whose allocator may otherwise hand the batch's memory out again).
+int cs_train_step_async(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float lr)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (!x || !y || batch <= 0) return fail(CS_ERR_INVALID, "x/y NULL or batch <= 0");
+    if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
+    if (!t->ref || kind == CS_MEM_HOST) {
+        // run-time-shaped architectures (their step synchronises by itself) and pageable host batches: a synchronous step,
+        // its scalars added on the host
+        float l = 0.0f, m = 0.0f;
+        int rc = cs_train_step(t, x, y, batch, kind, lr, &l, &m);
+        if (rc) return rc;
+        t->hacc[0] += l; t->hacc[1] += m; t->hacc[2] += 1.0;
+        HIPCHK(hipEventRecord(t->ev_in, t->stream));
+        return CS_OK;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    int rc = ensure_batch(t, batch);
+    if (rc) return rc;
+    if ((rc = copy_in(t, t->x, x, kind, (size_t)batch * kH * kW)) || (rc = copy_in(t, t->y, y, kind, (size_t)batch * kH * kW))) return rc;
+    HIPCHK(hipEventRecord(t->ev_in, t->stream));
+    if ((rc = fb_enqueue(t, batch))) return rc;
+    t->step += 1;
+    const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
+    const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+    LCHK(launch_adam(t->P.as<float>(), t->G, t->M.as<float>(), t->V.as<float>(), t->nparam, nullptr, t->cfg.beta1, t->cfg.beta2,
+                     t->cfg.adam_eps, t->stream, alpha, t->scal.as<float>(), t->macc.as<double>()));
+    return repack(t);
+}
+
+int cs_train_inputs_consumed(cs_trainer* t, void* hip_stream)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer handle is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, t->ev_in, 0));
+    return CS_OK;
+}
+
+// Mean loss / MAE over the steps since the last reset (Keras's epoch metrics), the number of steps; reset != 0 clears the sums.
+// Synchronises the handle's stream: the one host round trip of an epoch of cs_train_step_async calls.
+int cs_train_read_metrics(cs_trainer* t, double* loss_mean, double* mae_mean, int64_t* steps, int reset)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    HIPCHK(hipSetDevice(t->device));
+    double d[3] = {0.0, 0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(d, t->macc.p, sizeof d, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    const double n = d[2] + t->hacc[2];
+    if (loss_mean) *loss_mean = n > 0 ? (d[0] + t->hacc[0]) / n : 0.0;
+    if (mae_mean) *mae_mean = n > 0 ? (d[1] + t->hacc[1]) / n : 0.0;
+    if (steps) *steps = (int64_t)n;
+    if (reset) {
+        HIPCHK(hipMemsetAsync(t->macc.p, 0, sizeof d, t->stream));
+        t->hacc[0] = t->hacc[1] = t->hacc[2] = 0.0;
+    }
+    return CS_OK;
+}
+
 int cs_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae)
 {
     if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
@@ -422,7 +531,27 @@ int cs_train_augment(cs_trainer* t, const float* x, int64_t n, const cs_aug_affi
     const size_t bytes = (size_t)n * t->H * t->W * sizeof(float);
     int rc;
     if ((rc = t->aug_tf.ensure((size_t)n * sizeof(cs_aug_affine)))) return rc;
-    HIPCHK(hipMemcpyAsync(t->aug_tf.p, tf, (size_t)n * sizeof(cs_aug_affine), hipMemcpyHostToDevice, t->stream));
+    // the parameters travel through a pinned ring (the caller's array may be gone before an asynchronous copy reads it); a slot
+    // is reused only after the copy out of it has run
+    const size_t need = (size_t)n * sizeof(cs_aug_affine);
+    if (need > t->aug_pin_slot) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        if (t->aug_pin) { (void)hipHostFree(t->aug_pin); t->aug_pin = nullptr; }
+        HIPCHK(hipHostMalloc(&t->aug_pin, need * cs_trainer::AUG_SLOTS, hipHostMallocDefault));
+        t->aug_pin_slot = need;
+        for (int k = 0; k < cs_trainer::AUG_SLOTS; ++k) {
+            t->aug_used[k] = false;
+            if (!t->ev_aug[k]) HIPCHK(hipEventCreateWithFlags(&t->ev_aug[k], hipEventDisableTiming));
+        }
+    }
+    const int slot = t->aug_next;
+    t->aug_next = (slot + 1) % cs_trainer::AUG_SLOTS;
+    if (t->aug_used[slot]) HIPCHK(hipEventSynchronize(t->ev_aug[slot]));
+    char* pin = (char*)t->aug_pin + (size_t)slot * t->aug_pin_slot;
+    memcpy(pin, tf, need);
+    HIPCHK(hipMemcpyAsync(t->aug_tf.p, pin, need, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipEventRecord(t->ev_aug[slot], t->stream));
+    t->aug_used[slot] = true;
     const float* d_in = x;
     float* d_out = out;
     if (kind == CS_MEM_HOST) {
@@ -432,8 +561,13 @@ int cs_train_augment(cs_trainer* t, const float* x, int64_t n, const cs_aug_affi
         d_out = t->aug_out.as<float>();
     }
     LCHK(launch_augment(d_in, t->aug_tf.as<cs_aug_affine>(), d_out, n, t->H, t->W, t->stream));
-    if (kind == CS_MEM_HOST) HIPCHK(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, t->stream));
-    HIPCHK(hipStreamSynchronize(t->stream));
+    if (kind == CS_MEM_HOST) {
+        HIPCHK(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, t->stream));
+        HIPCHK(hipStreamSynchronize(t->stream));
+    }
+    // device output: left on the handle's stream (what consumes it next -- cs_train_step / cs_train_step_async -- runs there;
+    // any other reader orders itself with cs_train_inputs_consumed / a synchronising call)
+    HIPCHK(hipEventRecord(t->ev_in, t->stream));
     return CS_OK;
 }
 

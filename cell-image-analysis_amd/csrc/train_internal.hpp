@@ -39,9 +39,30 @@ struct cs_trainer {
     int64_t descs_batch = -1;
     float* hloss = nullptr;             // pinned {loss, mae, alpha staging, -}: read after the step's single synchronisation
     bool defer_sync = false;            // cs_train_step: forward_backward leaves its results to the sync at the end of apply
+    // cs_train_step_async: epoch metrics on the device {sum loss, sum mae, batches} (double), what synchronous generic steps add
+    // on the host, the event behind the step's input copies, and a pinned ring for the augmentation parameters
+    cs::DevBuf macc;
+    double hacc[3] = {0.0, 0.0, 0.0};
+    // synchronised BatchNormalization under data parallelism (cs_train_set_sync_bn): the caller's all-gather, its exchange buffer
+    cs_allgather_fn sync_fn = nullptr;
+    void* sync_ctx = nullptr;
+    float* sync_buf = nullptr;
+    int64_t sync_cap = 0;
+    int sync_rank = 0, sync_world = 1;
+    cs::DevBuf sync_scratch;
+    hipEvent_t ev_in = nullptr;
+    static constexpr int AUG_SLOTS = 8;
+    void* aug_pin = nullptr;
+    size_t aug_pin_slot = 0;            // bytes per slot
+    hipEvent_t ev_aug[AUG_SLOTS] = {nullptr};
+    bool aug_used[AUG_SLOTS] = {false};
+    int aug_next = 0;
     ~cs_trainer()
     {
         if (hloss) (void)hipHostFree(hloss);
+        if (aug_pin) (void)hipHostFree(aug_pin);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        for (auto& e : ev_aug) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_dz) if (e) (void)hipEventDestroy(e);
         if (ev_wg) (void)hipEventDestroy(ev_wg);
         if (stream2) (void)hipStreamDestroy(stream2);

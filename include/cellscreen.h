@@ -322,11 +322,35 @@ int cs_train_wait_stream(cs_trainer *t, void *hip_stream);
  * augmented image of datagen.flow(X_train, X_train), :287), y = target; [batch][H][W] fp32. */
 int cs_train_step(cs_trainer *t, const float *x, const float *y, int64_t batch, int kind, float lr,
                   float *loss, float *mae);
+/* The same batch with NO host synchronisation: copies, forward, backward, Adam and the operand re-pack are enqueued on the
+ * handle's stream and the call returns.  The batch's loss / mae are added to running sums on the device -- Keras's epoch
+ * metrics are the means over the epoch's batches (fit(), CAE_improved_modeltrain.py:286-293) -- and cs_train_read_metrics
+ * fetches them: one host round trip per epoch instead of one per step.  x / y must stay valid until the step's input copies
+ * have run; cs_train_inputs_consumed(t, stream) makes `stream` (the caller's, e.g. torch's current stream) wait for exactly
+ * that point, and likewise for the device output of the last cs_train_augment.  Host batches and run-time-shaped
+ * architectures fall back to a synchronous step whose scalars are added on the host. */
+int cs_train_step_async(cs_trainer *t, const float *x, const float *y, int64_t batch, int kind, float lr);
+int cs_train_inputs_consumed(cs_trainer *t, void *hip_stream);
+/* Mean loss / mae over the cs_train_step_async calls since the last reset, their number; reset != 0 clears the sums.
+ * Synchronises the handle's stream. */
+int cs_train_read_metrics(cs_trainer *t, double *loss_mean, double *mae_mean, int64_t *steps, int reset);
 /* The two halves of cs_train_step, for data-parallel training: gradients are left in the
  * gradient buffer (all-reduce it between the two calls). */
 int cs_train_forward_backward(cs_trainer *t, const float *x, const float *y, int64_t batch, int kind,
                               float *loss, float *mae);
 int cs_train_apply(cs_trainer *t, float lr);
+/* BatchNormalization over the WHOLE batch when the batch is split over `world` processes (the reference normalises over its
+ * single batch of 32, CAE_improved_modeltrain.py:192-213 with batch_size=32 at :287).  cs_train_forward_backward then stops at
+ * two points per BN layer -- after the layer's local {count, mean, M2} per channel (forward) and after its local
+ * {sum dy, sum dy xhat} (backward) -- writes this rank's floats_per_rank values at device_buf + rank * floats_per_rank,
+ * synchronises its stream and calls fn(ctx, floats_per_rank): the caller all-gathers in place (RCCL / torch.distributed; a
+ * fake communicator in tests) and returns 0 once device_buf[0 .. world * floats_per_rank) is complete and visible to the
+ * device.  The library merges the `world` triples in rank order (Chan's formula, double), so every rank gets identical
+ * statistics, identical moving averages, and -- with the usual mean of the per-rank weight gradients -- the gradient of the
+ * single-process step.  capacity_floats >= world * 3 * (largest filter count).  fn == NULL switches it off.  Reference graph
+ * only (CS_ERR_UNSUPPORTED otherwise). */
+typedef int (*cs_allgather_fn)(void *ctx, int64_t floats_per_rank);
+int cs_train_set_sync_bn(cs_trainer *t, cs_allgather_fn fn, void *ctx, float *device_buf, int64_t capacity_floats, int rank, int world);
 /* Use caller-owned device memory (n_trainable floats, e.g. a torch tensor) as the gradient
  * buffer; NULL restores the internal one. */
 int cs_train_set_grad_buffer(cs_trainer *t, float *device_buffer);
@@ -345,7 +369,9 @@ typedef struct cs_aug_affine {
     double off[2];
     int32_t identity, flip_h, flip_v, reserved;
 } cs_aug_affine;
-/* x, out: [n][64][64] fp32, both `kind`; tf: host array of n transforms.  out may not alias x. */
+/* x, out: [n][64][64] fp32, both `kind`; tf: host array of n transforms (copied before the call returns).  out may not
+ * alias x.  A CS_MEM_DEVICE output is left on the handle's stream (the next cs_train_step* consumes it there); any other
+ * reader orders itself with cs_train_inputs_consumed or a synchronising call.  CS_MEM_HOST returns when out is written. */
 int cs_train_augment(cs_trainer *t, const float *x, int64_t n, const cs_aug_affine *tf, float *out, int kind);
 
 /* Copies to host (each pointer may be NULL): trainable parameters, moving statistics, last gradients. */

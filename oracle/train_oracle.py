@@ -90,6 +90,7 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True, re
     cache = []
     h = x
     batch_mean, batch_var = [], []
+    margins = []          # per BN layer: how far the layer's discontinuous decisions are from flipping, relative to its range
     for l in range(st.n_conv):
         ups = l > st.n_enc
         cols = _im2col(h, ups)
@@ -110,16 +111,26 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True, re
             st.mov_mean[l] = st.mov_mean[l] * momentum + mu * (1 - momentum)
             st.mov_var[l] = st.mov_var[l] * momentum + var * (1 - momentum)
         c = dict(cols=cols, ups=ups, cin=h.shape[3], r=r, xhat=xhat, inv=inv)
+        mg = dict(relu=float(np.abs(z).min() / max(np.abs(z).max(), 1e-300)))   # min |z| over the layer / max |z|
         if l < st.n_enc:
             N, H, W, C = yb.shape
             win = yb.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(N, H // 2, W // 2, C, 4)
             arg = win.argmax(axis=-1)                                            # first max in (dy,dx) order
+            # smallest lead of a window's winner over its runner-up / max |BN out|, over the windows where the routing matters
+            # (a tie between two elements that ReLU zeroed sends the gradient to an element whose ReLU' is 0 either way)
+            order = np.argsort(win, axis=-1)
+            rwin = r.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(N, H // 2, W // 2, C, 4)
+            v1, v2 = np.take_along_axis(win, order[..., 3:4], -1), np.take_along_axis(win, order[..., 2:3], -1)
+            r1, r2 = np.take_along_axis(rwin, order[..., 3:4], -1), np.take_along_axis(rwin, order[..., 2:3], -1)
+            live = (r1 > 0) | (r2 > 0)
+            mg["pool"] = float((v1 - v2)[live].min() / max(np.abs(yb).max(), 1e-300)) if live.any() else 1.0
             if pool_args is not None and pool_args[l] is not None:
                 arg = np.asarray(pool_args[l])
             h = np.take_along_axis(win, arg[..., None], axis=-1)[..., 0]
             c["arg"] = arg
         else:
             h = yb
+        margins.append(mg)
         cache.append(c)
     n_el = out.size
     diff = out - y
@@ -157,7 +168,7 @@ def forward_backward(st: TrainState, x, y, momentum=0.99, update_moving=True, re
             dh = _col2im(dz @ K.T, c["cin"], c["ups"])
             das[l - 1] = dh
     return dict(loss=loss, mae=mae, out=out[..., 0], grads=grads, batch_mean=batch_mean, batch_var=batch_var,
-                dz=dzs, da=das, relu=[c.get("r") for c in cache])
+                dz=dzs, da=das, relu=[c.get("r") for c in cache], margins=margins)
 
 
 def adam_step(st: TrainState, grads, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):

@@ -72,3 +72,36 @@ def test_statistics_of_the_reference_generator():
     assert abs(np.mean([p["flip_h"] for p in ps]) - 0.5) < 0.03
     assert abs(np.mean([p["flip_v"] for p in ps]) - 0.5) < 0.03
     assert abs(np.mean([p["tx"] for p in ps])) < 0.05 and abs(np.mean([p["theta"] for p in ps])) < 0.08
+
+
+def test_vectorised_batch_draw_is_the_scalar_algebra():
+    """ImageDataGenerator.random_transforms (one numpy pass per batch, what an epoch of 1,250 x 32 draws uses) against the
+    per-image path on the SAME parameters, and the packed layout against the C ABI's struct."""
+    import ctypes as C
+    from cellscreen import _lib as L
+    gen = ImageDataGenerator.reference()
+    assert gen.AFFINE_DTYPE.itemsize == C.sizeof(L.CSAugAffine)
+    for f, (name, _t) in zip(gen.AFFINE_DTYPE.names, L.CSAugAffine._fields_):
+        assert f == name and gen.AFFINE_DTYPE.fields[f][1] == getattr(L.CSAugAffine, name).offset
+    rng = np.random.default_rng(0)
+    n = 200
+    th, tx, ty = rng.uniform(-2, 2, n), rng.uniform(-.02, .02, n), rng.uniform(-.02, .02, n)
+    zx, zy, u1, u2 = rng.uniform(.98, 1.02, n), rng.uniform(.98, 1.02, n), rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+
+    class Replay:                      # hands the arrays out in the order random_transforms asks for them
+        def __init__(self, seq):
+            self.seq = list(seq)
+
+        def uniform(self, lo, hi, size=None):
+            v = self.seq.pop(0)
+            assert len(v) == size and (v >= lo).all() and (v <= hi).all()
+            return v
+    arr = gen.random_transforms(n, (64, 64), Replay([th, tx, ty, zx, zy, u1, u2]))
+    for i in range(n):
+        p = dict(theta=th[i], tx=tx[i] * 64, ty=ty[i] * 64, zx=zx[i], zy=zy[i], flip_h=u1[i] < .5, flip_v=u2[i] < .5)
+        m, off = gen.affine(p, 64, 64)
+        assert np.abs(arr["m"][i].reshape(2, 2) - m).max() <= 1e-13 and np.abs(arr["off"][i] - off).max() <= 1e-12
+        assert arr["flip_h"][i] == int(p["flip_h"]) and arr["flip_v"][i] == int(p["flip_v"]) and arr["identity"][i] == 0
+    # no rotation / shift / zoom configured: every draw is the identity (+ flips)
+    flips = ImageDataGenerator(horizontal_flip=True).random_transforms(50, (64, 64), np.random.default_rng(1))
+    assert flips["identity"].all() and 5 < flips["flip_h"].sum() < 45 and not flips["flip_v"].any()

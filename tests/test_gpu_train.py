@@ -75,6 +75,36 @@ def test_forward_backward_gradients(n):
     tr.close()
 
 
+def test_gradients_against_the_unconstrained_oracle_on_a_batch_with_margins():
+    """one gradient check in which the oracle runs FREE -- it takes its own ReLU and max-pool decisions, nothing
+    is handed over from the trainer.  That is only meaningful on a batch whose every decision is safe from rounding: weights
+    seed 32 / blob crop 51 (found by a seeded search, oracle/train_oracle.py reports the margins) has every pre-activation at least
+    1.8e-6 of its layer's range away from 0 and every live pooling window's winner at least 3.9e-6 of the range ahead of its
+    runner-up -- the fp32 pre-activations are good to ~1e-7 (conv1, K = 9) .. 5e-7 (K = 288 / 576) of the range.  The margins are
+    asserted, then all 26 gradient tensors, the loss and the MAE must agree at the usual bars with NO pattern shared."""
+    w = synth.random_cae(seed=32)
+    y = synth.blob_crops(51, 1)
+    x = np.clip(y + 0.02 * np.random.default_rng(51).standard_normal(y.shape).astype(np.float32), 0, 1).astype(np.float32)
+    ref = T.forward_backward(T.TrainState(w, dtype=np.float64), x, y, update_moving=False)
+    worst = min(min(m.values()) for m in ref["margins"])
+    assert worst >= 1.5e-6, ref["margins"]
+    tr = Trainer(w)
+    try:
+        loss, mae = tr.forward_backward(x, y)
+        masks, _ = activation_pattern(tr, w, 1)
+        assert all(np.array_equal(m, r > 0) for m, r in zip(masks[:6], ref["relu"][:6]))      # the same decisions, taken independently
+        assert abs(loss - ref["loss"]) <= 1e-5 * ref["loss"] and abs(mae - ref["mae"]) <= 1e-5 * ref["mae"]
+        _, _, g = tr.export_flat(grads=True)
+        got = grads_by_name(g)
+        errs = {name: np.linalg.norm(got[name].astype(np.float64) - gr) / max(np.linalg.norm(gr), 1e-30)
+                for (name, _shape), gr in zip(param_layout(), ref["grads"])}
+        print("free-oracle gradient relative L2 errors:", {k: float("%.2e" % v) for k, v in errs.items()})
+        for name, err in errs.items():
+            assert err <= TOL_GRAD, f"{name}: relative L2 error {err:.3e}"
+    finally:
+        tr.close()
+
+
 def test_adam_update_is_keras_formula():
     """cs_train_apply on the trainer's own gradients == Keras Adam evaluated in float64:
     alpha = lr*sqrt(1-b2^t)/(1-b1^t); m, v EMAs; w -= alpha*m/(sqrt(v)+1e-7)."""
@@ -96,6 +126,41 @@ def test_adam_update_is_keras_formula():
         assert np.abs(got - p).max() <= 2e-6 * 1e-3 + 1e-6 * np.abs(p).max(), t     # updates are O(lr)
         p = got.astype(np.float64)   # follow the trainer so the next step checks one update in isolation
     tr.close()
+
+
+def test_asynchronous_steps_are_the_synchronous_steps():
+    """cs_train_step_async (no host synchronisation, loss / MAE summed on the device, alpha passed by value) against
+    cs_train_step on a twin trainer: the same weights bit for bit after several steps, Keras's epoch metrics = the mean of the
+    per-step scalars, device-side augmentation in the loop, and a reset that clears the sums."""
+    import torch
+    from cellscreen.augment import ImageDataGenerator
+    w = synth.random_cae(seed=12, trivial_bn=True)
+    a, b = Trainer(w), Trainer(w)
+    gen = ImageDataGenerator.reference()
+    X = torch.from_numpy(synth.blob_crops(4, 96)).cuda()
+    losses, maes = [], []
+    try:
+        for i in range(6):
+            yb = X[16 * i:16 * i + 16]
+            tf = gen.random_transforms(16, (64, 64), np.random.default_rng(i))
+            xa = a.augment(yb, tf)
+            l, m = a.step(xa, yb, 1e-3)
+            losses.append(l); maes.append(m)
+            b.step_async(b.augment(yb, tf), yb, 1e-3)
+            del xa                                                   # the allocator may hand these bytes out again at once
+            junk = torch.full((16, 64, 64), float("nan"), device="cuda")    # ... to this: the steps must have read them before
+            del junk
+        lo, ma, n = b.read_metrics(reset=True)
+        assert n == 6 and abs(lo - np.mean(losses)) <= 1e-6 * abs(lo) and abs(ma - np.mean(maes)) <= 1e-6 * abs(ma)
+        pa, ma_ = a.export_flat()
+        pb, mb_ = b.export_flat()
+        assert np.array_equal(pa, pb) and np.array_equal(ma_, mb_)
+        assert b.read_metrics()[2] == 0
+        # host batches fall back to a synchronous step and still count
+        b.step_async(synth.blob_crops(5, 8), synth.blob_crops(5, 8), 1e-3)
+        assert b.read_metrics()[2] == 1
+    finally:
+        a.close(); b.close()
 
 
 def test_training_trajectory_tracks_the_oracle():
