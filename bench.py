@@ -47,6 +47,12 @@ import subprocess
 import sys
 import time
 
+# HIP deals its streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share one run
+# their work in submission order.  This process has more than four (torch's, each handle's compute and copy streams, the
+# e2e leg's upload stream): measured on the e2e_raw leg, the upload of chunk i + 1 and the preprocess kernel of chunk i
+# landed on one queue and ran one after the other (2.1 M cells/s; 3.1 M with 8 queues).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "cell-image-analysis_amd"), os.path.join(ROOT, "tools"), ROOT):
     if p not in sys.path:
@@ -402,16 +408,22 @@ def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
             d_pix[ci & 1][:hi - lo].copy_(host[lo:hi], non_blocking=True)
             evs[ci & 1].record(copy_stream)
 
+    # NOT torch's default stream: that is the legacy null stream, and every operation on it (the event the wrappers record to
+    # order the library after torch, the wait below) is a barrier against all blocking streams -- the upload of chunk i + 1 on
+    # the copy stream would be waited for before chunk i's kernels start (measured: 0.47 s = upload + preprocess + screen)
+    main_stream = torch.cuda.Stream(device=dev)
+
     def run():
-        copy_in(0)
-        for ci, (a, b) in enumerate(bounds):
-            if ci + 1 < len(bounds):
-                copy_in(ci + 1)            # the other buffer: its last reader (chunk ci - 1's preprocess) has returned
-            torch.cuda.current_stream().wait_event(evs[ci & 1])
-            proc.run_packed(d_pix[ci & 1], off[a:b] - off[a], hs[a:b], ws[a:b], out=d_crops[:b - a])
-            eng.screen(d_crops[:b - a], out={k: v[a:b] for k, v in out.items()}, out_device=True)
-        for k in out:
-            res[k].copy_(out[k], non_blocking=True)
+        with torch.cuda.stream(main_stream):
+            copy_in(0)
+            for ci, (a, b) in enumerate(bounds):
+                if ci + 1 < len(bounds):
+                    copy_in(ci + 1)            # the other buffer: its last reader (chunk ci - 1's preprocess) has returned
+                main_stream.wait_event(evs[ci & 1])
+                proc.run_packed(d_pix[ci & 1], off[a:b] - off[a], hs[a:b], ws[a:b], out=d_crops[:b - a])
+                eng.screen(d_crops[:b - a], out={k: v[a:b] for k, v in out.items()}, out_device=True)
+            for k in out:
+                res[k].copy_(out[k], non_blocking=True)
         torch.cuda.synchronize()
 
     try:
@@ -423,7 +435,7 @@ def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
         proc.close()
     return dict(value=round(n / dt, 1), unit="cells/s", wall_s=round(dt, 4), crops=n, chunk_crops=chunk,
                 h2d_bytes_per_cell=round(2.0 * total / n, 1), d2h_bytes_per_cell=18,
-                h2d_gbs=round(2.0 * total / dt / 1e9, 2),
+                h2d_gbs=round(2.0 * total / dt / 1e9, 2), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
                 workload="%d raw uint16 crops, sides U[32,100] (4,096 distinct, repeated), pinned host -> cs_preprocess -> cs_screen -> host" % n,
                 anomaly_rate_conservative=round(float((res["cons_pred"] == -1).float().mean()), 4))
 

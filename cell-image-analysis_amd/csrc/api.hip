@@ -34,8 +34,8 @@ struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
     DevBuf c12w1, c12w1x3; // conv1's fragments for the fused kernel (negated for filters with a negative BN scale); x3: its bf16 form
     DevBuf c3x3, c4x3, c5x3, c6x3;   // conv3's Winograd U / conv4's / conv5's / conv6's weights as three bf16 planes
-    DevBuf c4h2, c5h2, c6h2;         // conv4's / conv5's / conv6's (folded) weights as two fp16 planes (the *_h2 kernels) ...
-    float c4h2_inv = 1.0f, c5h2_inv = 1.0f, c6h2_inv = 1.0f;   // ... and 1 / their power-of-two scales
+    DevBuf c3h2, c4h2, c5h2, c6h2;   // conv3's Winograd U / conv4's / conv5's / conv6's (folded) weights as two fp16 planes (the *_h2 kernels) ...
+    float c3h2_inv = 1.0f, c4h2_inv = 1.0f, c5h2_inv = 1.0f, c6h2_inv = 1.0f;   // ... and 1 / their power-of-two scales
     DevBuf c12h2;          // the same U as two fp16 planes (C2H form of the fused kernel) ...
     float c12h2_inv = 1.0f, p1a = 0.0f, p1b = 0.0f;   // ... 1 / their scale, and the bound max|p1| <= p1a max|x| + p1b
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
@@ -87,6 +87,7 @@ struct cs_model {
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
     bool h2conv6 = getenv("CS_NO_FP16X2_CONV6") == nullptr; // A/B knob: conv6 (in the fused conv6 + conv7 kernel) alone
+    bool h2conv3 = getenv("CS_NO_FP16X2_CONV3") == nullptr; // conv3's Winograd contraction alone
     bool h2conv2 = getenv("CS_NO_FP16X2_CONV2") == nullptr; // conv2 inside the fused conv1 + conv2 kernel alone
     bool h2conv4 = getenv("CS_NO_FP16X2_CONV4") == nullptr, h2conv5 = getenv("CS_NO_FP16X2_CONV5") == nullptr;   // conv4 / conv5 alone
     bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
@@ -256,6 +257,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             std::vector<uint16_t> planes(pack_wino3_x3(nullptr, nullptr));
             pack_wino3_x3(w->kernel[l], planes.data());
             rc = upload(set.c3x3, planes.data(), planes.size() * sizeof(uint16_t));
+            if (rc) return rc;
+            std::vector<uint16_t> h2(pack_wino3_h2(nullptr, nullptr, nullptr));
+            pack_wino3_h2(w->kernel[l], h2.data(), &set.c3h2_inv);
+            rc = upload(set.c3h2, h2.data(), h2.size() * sizeof(uint16_t));
             if (rc) return rc;
         }
         if (l == 3) {
@@ -560,6 +565,11 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_up(l, in, set.winoup[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
+            continue;
+        }
+        if (l == 2 && m->wino3 && m->use_wino && m->bf16x3 && m->x3conv3 && m->fp16x2 && m->h2conv3) {
+            LAUNCH(K_CONV3, nc,
+                   launch_conv3_wino_h2(in, set.c3h2.as<uint16_t>(), set.c3h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
         if (l == 2 && m->wino3 && m->use_wino && m->bf16x3 && m->x3conv3) {
@@ -1273,7 +1283,8 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
     }
     if (m->arch.ref) {
         if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * ((m->fp16x2 && m->h2conv4) ? 3 : 6);   // 4 tiles x 2 slices x 9 taps x 6 (bf16 split) or 3 (fp16 split) products
-        if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3) v = 16.0 * 4 * 2 * 2 * 6;   // 16 points x 4 tile groups x 2 slices x 2 blocks x 6
+        if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3)      // 16 points x 4 tile groups x 2 slices x 2 blocks x 6 (bf16 split) | 3 (fp16 split)
+            v = 16.0 * 4 * 2 * 2 * ((m->fp16x2 && m->h2conv3) ? 3 : 6);
         if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1)               // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs;
             v = 66 * 8 * 3 + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * ((m->fp16x2 && m->h2conv5) ? 3 : 6);   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 | 3 products

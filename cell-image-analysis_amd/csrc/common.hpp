@@ -41,6 +41,10 @@ size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
 // conv3 (layer 2) in the same Winograd form with the contraction on the bf16 matrix pipe (six split products), one wave per SIMD
 hipError_t launch_conv3_wino_x3(const float* in, const uint16_t* uplanes, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
 size_t pack_wino3_x3(const float* hwio, uint16_t* dst);       // returns the number of bf16 values
+// ... and as a two-term fp16 split (three products, two workgroups per CU): planes + 1 / (their power-of-two scale)
+hipError_t launch_conv3_wino_h2(const float* in, const uint16_t* uplanes, float inv_sw, const float* ep, float* out, int64_t n_cells,
+                                hipStream_t stream);
+size_t pack_wino3_h2(const float* hwio, uint16_t* dst, float* inv_sw);
 // conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
 // pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
 // w1x3 (optional, pack_conv12_conv1_x3): conv1 runs on bf16 MFMAs (the three bf16 planes of the crop packed along K)
@@ -159,6 +163,7 @@ int conv_generic_folds(int H, int W, int cin, int cout);
 // run-time-shaped training kernels (train_generic.hip)
 hipError_t launch_flip_transpose(const float* hwio, int cin, int cout, float* dst, hipStream_t s);
 hipError_t launch_sumpool2x2(const float* in, float* out, int64_t n, int H, int W, int C, hipStream_t s);
+size_t wgrad_generic_lds_bytes(int W, int cin, int cout);
 hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, int64_t n, int H, int W, int cin, int cout, int ups,
                                 int max_parts, int* nparts, hipStream_t s);
 hipError_t launch_recon_err(const float* recon, const float* x, int64_t n, int npix, float* errpart, hipStream_t stream);

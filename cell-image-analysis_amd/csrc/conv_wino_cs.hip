@@ -17,8 +17,10 @@
 // VALU work drop 4x; the price is the exchange and a second barrier per group.
 #include "common.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace cs {
 
@@ -455,6 +457,222 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_x3_kernel(const float* __re
     }
 }
 
+// ---- conv3 with the Winograd-domain contraction as a TWO-term fp16 split (three products) ---------------------------------
+// conv_wino_up.hip (conv67_h2_kernel) has the algebra and the hardware facts; tests/study_split_fp16.py measures conv3 in this form
+// at 2.6e-7 of the feature range (the fp32 MFMA chain: 5.2e-7).  The decomposition is conv3_wino_x3_kernel's, with half the matrix
+// instructions (768 per cell), a 3-instruction split per transformed value instead of 5.5, and U as two fp16 planes in 128 VGPRs --
+// which lets TWO workgroups share a CU (two waves per SIMD: one workgroup's barriers and split bursts under the other's MFMAs),
+// where the bf16 form's 192 weight registers allowed one.
+//   scale   |V| <= 4 max|p2| (B^T of F(2,3) has absolute row sums 2): S puts 4 max|p2| of the STRIP into [2^14, 2^15); the
+//           maximum is taken where the next strip is staged (registers -> DPP row max -> LDS atomic max, read behind the
+//           barrier that is there anyway).  The strip itself stays fp32 in LDS (the transform runs in fp32); V S is split in
+//           registers; 1 / (S S_w) is applied with the bias in the epilogue's fma.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct W3H {
+    using C = WinoL3;
+    static constexpr int OFF_MAX = 2 * W3X::STRIP + C::XCH;        // two words: strip maxima, alternating
+    static constexpr int LDS = OFF_MAX + 16;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+__device__ __forceinline__ unsigned int w3h_rowmax(unsigned int m)
+{
+    unsigned int o;
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [1,0,3,2]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [2,3,0,1]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:4
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:8
+    return m;
+}
+// S = the power of two that puts 4 x (a maximum with float bits mbits) into [2^14, 2^15), and 1 / S (exponents clamped so that
+// both stay normal floats)
+__device__ __forceinline__ void w3h_scale(unsigned int mbits, float& S, float& invS)
+{
+    int E = (int)((mbits >> 23) & 0xffu) + 2;
+    E = E < 40 ? 40 : (E > 254 ? 254 : E);
+    S = __builtin_bit_cast(float, (unsigned int)(268 - E) << 23);
+    invS = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23);
+}
+__device__ __forceinline__ void w3h_split8(const f32x4& lo4, const f32x4& hi4, float S, f16x8& ah, f16x8& al)
+{
+    const f32x4 a = lo4 * S, b = hi4 * S;
+    const f16x4 ha = __builtin_convertvector(a, f16x4), hb = __builtin_convertvector(b, f16x4);
+    const f32x4 ra = a - __builtin_convertvector(ha, f32x4), rb = b - __builtin_convertvector(hb, f32x4);     // exact in fp32
+    const f16x4 la = __builtin_convertvector(ra, f16x4), lb = __builtin_convertvector(rb, f16x4);
+    ah = f16x8{ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+    al = f16x8{la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_wino_h2_kernel(const float* __restrict__ in, const f16x8* __restrict__ ufrag,
+                                                              const float* __restrict__ ep /* [3][32] */, float* __restrict__ out,
+                                                              long n_cells, float inv_sw)
+{
+    using C = WinoL3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const xch = (float*)(smem + 2 * W3X::STRIP);
+    unsigned int* const mxw = (unsigned int*)(smem + W3H::OFF_MAX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = transform-domain column
+    const int li = lane & 15, kq = lane >> 4;
+
+    f16x8 B[4][C::NS][W3X::NKB][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int kb = 0; kb < W3X::NKB; ++kb)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) B[r][s][kb][p] = ufrag[(((((size_t)wc * 4 + r) * C::NS + s) * W3X::NKB + kb) * 2 + p) * 64 + lane];
+
+    const int ca = wc == 0 ? 0 : (wc == 2 ? 2 : 1);
+    const int cb = wc == 2 ? 1 : (wc == 3 ? 3 : 2);
+    const float sg = wc == 1 ? 1.0f : -1.0f;
+    const int trow = li / C::TW, tcol = li % C::TW;
+    const int poff = (2 * trow) * W3X::ROWP + (2 * tcol) * C::PS + 4 * kq;
+
+    const int fs = wc % C::NS, rbase = (wc / C::NS) * C::FR;
+    const int co = fs * 16 + li;
+    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
+
+    const long total = n_cells * C::NGRP;
+    const long first = blockIdx.x;
+    if (first >= total) return;
+    const int spx = tid / C::C4, sc4 = tid % C::C4;
+    const int goff = spx * C::CIN + sc4 * 4, loff = (spx + 1) * C::PS + sc4 * 4;
+    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::H * C::W * C::CIN; };
+    // the staged value of row r (zero outside the image) and its share of the strip's max|.|
+    auto st_prep = [&](int y0, int r, f32x4 v, unsigned int& mx) {
+        const int sy = y0 - 1 + r;
+        if (sy < 0 || sy >= C::H) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float a = v[0], b = v[1], c = v[2], d = v[3];         // scalars first (see conv45_bf16x3.hip, h2_absmax4)
+        const unsigned int u = __builtin_bit_cast(unsigned int, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
+        mx = mx > u ? mx : u;
+        return v;
+    };
+    for (int i = tid; i < W3H::LDS / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    float S, invS;
+    {
+        unsigned int mx = 0;
+#pragma unroll
+        for (int r = 0; r < C::R; ++r) {
+            const f32x4 v = st_prep((int)(first % C::NGRP) * C::SR, r, wn_load<C>(cell_ptr(first / C::NGRP), (int)(first % C::NGRP) * C::SR, r, goff), mx);
+            *(f32x4*)((float*)smem + r * W3X::ROWP + loff) = v;
+        }
+        mx = w3h_rowmax(mx);
+        if (li == 0) atomicMax(&mxw[0], mx);
+        __syncthreads();
+        w3h_scale(mxw[0], S, invS);
+        __syncthreads();
+        if (tid == 0) mxw[0] = 0;
+    }
+
+    f32x4 stg[C::NLD];
+    int buf = 0;
+    int k = 0;                                                     // strips staged so far: word (k + 1) & 1 collects the next maximum
+    for (long item = first; item < total; item += gridDim.x, ++k) {
+        const long cell = item / C::NGRP;
+        const int grp = (int)(item % C::NGRP);
+        const long nitem = item + gridDim.x;
+        const bool has_next = nitem < total;
+        const float* strip = (const float*)(smem + buf * W3X::STRIP);
+        float* nstrip = (float*)(smem + (buf ^ 1) * W3X::STRIP);
+        unsigned int* const mword = mxw + ((k + 1) & 1);
+        const float unscale = invS * inv_sw;
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) stg[j] = wn_load<C>(cell_ptr(nitem / C::NGRP), (int)(nitem % C::NGRP) * C::SR, j, goff);
+        }
+        const float* da_p = strip + poff + ca * C::PS;
+        const float* db_p = strip + poff + cb * C::PS;
+        f32x4 acc[C::NS][4];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kb = 0; kb < W3X::NKB; ++kb) {
+            // V[:, c] of the lane's 8 channels: halves h = channels 32 kb + 16 h + 4 kq .. +3
+            f32x4 v[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 da = *(const f32x4*)(da_p + i * W3X::ROWP + 32 * kb + 16 * h);
+                    const f32x4 db = *(const f32x4*)(db_p + i * W3X::ROWP + 32 * kb + 16 * h);
+                    w[i] = da + sg * db;
+                }
+                v[0][h] = w[0] - w[2]; v[1][h] = w[1] + w[2]; v[2][h] = w[2] - w[1]; v[3][h] = w[1] - w[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f16x8 ah, al;
+                w3h_split8(v[r][0], v[r][1], S, ah, al);
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    f32x4 d = acc[s][r];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[r][s][kb][1], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[r][s][kb][0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[r][s][kb][0], d, 0, 0, 0);
+                    acc[s][r] = d;
+                }
+            }
+        }
+        // row fold s = A^T M of each slice, left in LDS for the column fold
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+            f32x4 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = (acc[s][0][r] + acc[s][1][r]) + acc[s][2][r];
+                s1[r] = (acc[s][1][r] - acc[s][2][r]) - acc[s][3][r];
+            }
+            float* x = xch + ((size_t)((wc * C::NS + s) * 2) * 64 + lane) * 4;
+            *(f32x4*)x = s0;
+            *(f32x4*)(x + 64 * 4) = s1;
+        }
+        if (has_next) {
+            unsigned int mx = 0;
+#pragma unroll
+            for (int j = 0; j < C::NLD; ++j) {
+                stg[j] = st_prep((int)(nitem % C::NGRP) * C::SR, j, stg[j], mx);
+                *(f32x4*)(nstrip + j * W3X::ROWP + loff) = stg[j];
+            }
+            mx = w3h_rowmax(mx);
+            if (li == 0) atomicMax(mword, mx);
+        }
+        __syncthreads();   // s of all four columns in LDS; this strip fully read; next strip and its maximum complete
+        if (has_next) w3h_scale(*mword, S, invS);
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* x = xch + ((size_t)((c * C::NS + fs) * 2) * 64 + lane) * 4;
+            t0[c] = *(const f32x4*)x;
+            t1[c] = *(const f32x4*)(x + 64 * 4);
+        }
+        const f32x4 y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+        const f32x4 y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+        auto post = [&](float v) { v = fmaxf(fmaf(v, unscale, bias), 0.0f); return fmaf(v, bns, bnt); };
+#pragma unroll
+        for (int rr = 0; rr < C::FR; ++rr) {
+            const float a = rbase ? y00[2 + rr] : y00[rr], b = rbase ? y01[2 + rr] : y01[rr];
+            const float c2 = rbase ? y10[2 + rr] : y10[rr], d = rbase ? y11[2 + rr] : y11[rr];
+            const float mx = fmaxf(fmaxf(a, b), fmaxf(c2, d)), mn = fminf(fminf(a, b), fminf(c2, d));
+            const float res = post(bns >= 0.0f ? mx : mn);
+            const int t = 4 * kq + rbase + rr;
+            const int ty = grp * C::TR + t / C::TW, tx = t % C::TW;
+            out[(((size_t)cell * (C::H / 2) + ty) * (C::W / 2) + tx) * C::COUT + co] = res;
+        }
+        __syncthreads();   // exchange area free again; every thread has read this strip's maximum
+        if (tid == 0) *mword = 0;
+        buf ^= 1;
+    }
+}
+
 // ---- conv2 with a ring of staged rows --------------------------------------------------------------
 // Consecutive 16-tile groups of a cell (one tile row = 2 conv rows each) share two of their four staged rows.
 // The strip double buffer above reloads all four; here a workgroup walks whole cells and keeps the staged rows
@@ -753,6 +971,63 @@ hipError_t launch_conv3_wino_x3(const float* in, const uint16_t* uplanes, const 
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     hipLaunchKernelGGL(conv3_wino_x3_kernel, dim3(grid), dim3(256), W3X::LDS, stream, in, (const bf16x8*)uplanes, ep, out, (long)n_cells);
+    return hipGetLastError();
+}
+
+// conv3's U = G g G^T (double, rounded once to fp32) as two fp16 planes of S_w U in conv3_wino_h2_kernel's order:
+// [wave c][r][slice][channel block][plane 2][lane][8], the element order of pack_wino3_x3; *inv_sw = 1 / S_w
+size_t pack_wino3_h2(const float* hwio /* [3][3][64][32] */, uint16_t* dst, float* inv_sw)
+{
+    using C = WinoL3;
+    const size_t total = (size_t)4 * 4 * C::NS * W3X::NKB * 2 * 64 * 8;
+    if (!dst) return total;
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> U((size_t)16 * C::CIN * C::COUT);
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            for (int ci = 0; ci < C::CIN; ++ci)
+                for (int co = 0; co < C::COUT; ++co) {
+                    double u = 0.0;
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) u += G[r][a] * (double)hwio[((size_t)(a * 3 + b) * C::CIN + ci) * C::COUT + co] * G[c][b];
+                    U[((size_t)(r * 4 + c) * C::CIN + ci) * C::COUT + co] = (float)u;
+                }
+    const float S = f16x2_weight_scale(U.data(), U.size());
+    if (inv_sw) *inv_sw = 1.0f / S;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < C::NS; ++s)
+                for (int kb = 0; kb < W3X::NKB; ++kb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int li = lane & 15, kq = lane >> 4, co = 16 * s + li;
+                            const int ci = 32 * kb + (j < 4 ? 4 * kq + j : 16 + 4 * kq + j - 4);
+                            uint16_t pl[2];
+                            f16x2_split(U[((size_t)(r * 4 + c) * C::CIN + ci) * C::COUT + co], S, pl[0], pl[1]);
+                            for (int p = 0; p < 2; ++p)
+                                dst[((((((size_t)c * 4 + r) * C::NS + s) * W3X::NKB + kb) * 2 + p) * 64 + lane) * 8 + j] = pl[p];
+                        }
+    return total;
+}
+
+hipError_t launch_conv3_wino_h2(const float* in, const uint16_t* uplanes, float inv_sw, const float* ep, float* out, int64_t n_cells,
+                                hipStream_t stream)
+{
+    static int resident = 0;
+    if (!resident) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3_wino_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3H::LDS);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv3_wino_h2_kernel, 256, W3H::LDS)) != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
+    }
+    const long total = (long)n_cells * WinoL3::NGRP;
+    if (total <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    hipLaunchKernelGGL(conv3_wino_h2_kernel, dim3(grid), dim3(256), W3H::LDS, stream, in, (const f16x8*)uplanes, ep, out, (long)n_cells, inv_sw);
     return hipGetLastError();
 }
 

@@ -413,9 +413,15 @@ struct cs_preproc {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf pix, desc, clahe, out;
+    DevBuf pix, clahe, out;
+    // crop descriptors: pinned host memory the kernel reads directly (24 B per crop).  A host-to-device COPY of them would
+    // queue on the DMA engine behind whatever the caller has in flight there -- e.g. the raw pixels of the NEXT chunk it is
+    // uploading while this one computes -- and the kernel would start only when that upload has finished.
+    void* hdesc = nullptr;
+    const void* ddesc = nullptr;        // the same memory as the device sees it
     double last_kernel_ms = 0.0;
     int64_t last_pixels = 0;
+    ~cs_preproc() { if (hdesc) (void)hipHostFree(hdesc); }
 };
 
 static const int64_t kChunkPixels = 256ll << 20;        // pixel span of one launch (staging + uint16 plane)
@@ -432,9 +438,11 @@ int cs_preproc_create(int device_id, cs_preproc** out)
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+    if (e == hipSuccess) e = hipHostMalloc(&p->hdesc, (size_t)kChunkCrops * sizeof(CropDesc), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->ddesc, p->hdesc, 0);
     if (e != hipSuccess) {
         delete p;
-        return fail(CS_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+        return fail(CS_ERR_HIP, "stream / event / pinned descriptor buffer creation failed: %s", hipGetErrorString(e));
     }
     *out = p;
     return CS_OK;
@@ -494,7 +502,7 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
 
     p->last_kernel_ms = 0.0;
     p->last_pixels = 0;
-    std::vector<CropDesc> hdesc;
+    CropDesc* const hdesc = (CropDesc*)p->hdesc;     // free: every launch below is followed by a stream synchronisation
     int64_t i0 = 0;
     while (i0 < n) {
         // a chunk: consecutive crops, bounded in count and in the pixel span the fp64 planes must cover
@@ -512,7 +520,6 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
         }
         const int64_t nc = i1 - i0, span = hi - lo;
         if (span > (1ll << 31)) return fail(CS_ERR_UNSUPPORTED, "crops of one chunk are spread over more than 2^31 pixels");
-        hdesc.resize((size_t)nc);
         for (int64_t i = 0; i < nc; ++i) hdesc[(size_t)i] = CropDesc{(long long)(offsets[i0 + i] - lo), heights[i0 + i], widths[i0 + i]};
 
         int rc;
@@ -524,15 +531,15 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
             HIPCHK(hipMemcpyAsync(p->pix.p, (const char*)pixels + (size_t)lo * esz, (size_t)span * esz, hipMemcpyHostToDevice, p->stream));
             d_pix = (const char*)p->pix.p;
         }
-        if ((rc = p->desc.ensure((size_t)nc * sizeof(CropDesc)))) return rc;
-        HIPCHK(hipMemcpyAsync(p->desc.p, hdesc.data(), (size_t)nc * sizeof(CropDesc), hipMemcpyHostToDevice, p->stream));
         unsigned short* d_clahe;
         if (clahe_out && out_kind == CS_MEM_DEVICE) {
             d_clahe = clahe_out + lo;
         } else {
             if ((rc = p->clahe.ensure((size_t)span * sizeof(unsigned short)))) return rc;
             d_clahe = p->clahe.as<unsigned short>();
-            HIPCHK(hipMemsetAsync(d_clahe, 0, (size_t)span * sizeof(unsigned short), p->stream));   // gaps between crops read 0
+            // gaps between crops read 0 -- only when the plane goes back to the caller: a crop reads nothing but its own region,
+            // and a fill is DMA work that would queue behind whatever upload the caller has in flight (see hdesc above)
+            if (clahe_out) HIPCHK(hipMemsetAsync(d_clahe, 0, (size_t)span * sizeof(unsigned short), p->stream));
         }
         float* d_out;
         if (out_kind == CS_MEM_DEVICE) {
@@ -546,11 +553,11 @@ int cs_preprocess(cs_preproc* p, const void* pixels, int pixel_type, int64_t n_p
         if (pixel_type == CS_PIX_U8) {
             HIPCHK(hipFuncSetAttribute((const void*)preprocess_kernel<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3((unsigned)nc), dim3(PP_THREADS), lds, p->stream,
-                               (const unsigned char*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, d_out);
+                               (const unsigned char*)d_pix, (const CropDesc*)p->ddesc, clip_limit, d_clahe, d_out);
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)preprocess_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(preprocess_kernel<unsigned short>, dim3((unsigned)nc), dim3(PP_THREADS), lds, p->stream,
-                               (const unsigned short*)d_pix, p->desc.as<CropDesc>(), clip_limit, d_clahe, d_out);
+                               (const unsigned short*)d_pix, (const CropDesc*)p->ddesc, clip_limit, d_clahe, d_out);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(p->ev1, p->stream));

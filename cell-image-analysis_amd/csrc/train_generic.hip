@@ -199,6 +199,13 @@ static void wgrad_generic_shape(int cin, int cout, int* nco, int* wg_per_part)
     *wg_per_part = (tm * ((tn + *nco - 1) / *nco) + 3) / 4;
 }
 
+// bytes of LDS the weight-gradient kernel stages for a layer (three input rows + one dz row, padded pixel strides)
+size_t wgrad_generic_lds_bytes(int W, int cin, int cout)
+{
+    auto pad = [](int c) { return c + ((48 - (c & 31)) & 31); };
+    return ((size_t)3 * (W + 2) * pad(cin) + (size_t)W * pad(cout)) * sizeof(float);
+}
+
 hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, int64_t n, int H, int W, int cin, int cout, int ups,
                                 int max_parts, int* nparts, hipStream_t s)
 {
@@ -292,6 +299,10 @@ int gen_train_repack(cs_trainer* t)
 int gen_train_ensure_batch(cs_trainer* t, int64_t b)
 {
     if (b <= t->maxb) return CS_OK;
+    for (int l = 0; l < t->n_conv - 1; ++l)      // the BatchNormalization / pooling kernels index with 32-bit shifts and masks
+        if ((double)b * (double)t->rfl[l] >= 2147483648.0)
+            return fail(CS_ERR_UNSUPPORTED, "a batch of %lld cells makes conv %d's tensor %g elements: the BatchNormalization kernels index below 2^31",
+                        (long long)b, l, (double)b * (double)t->rfl[l]);
     int rc;
     const size_t npix = (size_t)t->H * t->W;
     if ((rc = t->x.ensure(b * npix * 4)) || (rc = t->y.ensure(b * npix * 4))) return rc;
@@ -400,10 +411,25 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
     return CS_OK;
 }
 
+// evaluation needs the forward tensors only: x, y, the stored activations, the output and the error partials -- not the
+// relu / gradient buffers of a training batch (~15 GB at 1,024 cells of the 128 x 128 variant)
+static int gen_eval_ensure(cs_trainer* t, int64_t b)
+{
+    if (b <= t->maxb || b <= t->eval_maxb) return CS_OK;
+    int rc;
+    const size_t npix = (size_t)t->H * t->W;
+    if ((rc = t->x.ensure(b * npix * 4)) || (rc = t->y.ensure(b * npix * 4))) return rc;
+    for (int l = 0; l < t->n_conv - 1; ++l)
+        if ((rc = t->a[l].ensure(b * t->afl[l] * 4))) return rc;
+    if ((rc = t->out.ensure(b * npix * 4)) || (rc = t->errpart.ensure((size_t)b * 8 * 4))) return rc;
+    t->eval_maxb = b;
+    return CS_OK;
+}
+
 int gen_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae)
 {
     const int64_t ch = n < 1024 ? n : 1024;
-    int rc = gen_train_ensure_batch(t, ch);
+    int rc = gen_eval_ensure(t, ch);
     if (rc) return rc;
     hipStream_t s = t->stream;
     float* P = t->P.as<float>();

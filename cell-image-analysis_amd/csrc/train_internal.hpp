@@ -12,6 +12,7 @@ struct cs_trainer {
     hipEvent_t ev_dz[TR_MAXL] = {nullptr}, ev_wg = nullptr;
     cs_train_cfg cfg;
     int64_t maxb = 0;
+    int64_t eval_maxb = 0;              // generic trainer: cells the forward-only buffers of cs_train_eval hold
     // architecture: ref = the reference graph (64x64, 32-64-32 | 32-64-32-1) on the tuned kernels
     bool ref = true;
     int H = 64, W = 64, n_conv = 7, n_enc = 3;

@@ -108,6 +108,14 @@ class _StubTrainer:
         self.lrs.append(lr)
         return 0.1, 0.1
 
+    def step_async(self, x, y, lr):
+        self.lrs.append(lr)
+        self.nsteps = getattr(self, "nsteps", 0) + 1
+
+    def read_metrics(self, reset=True):
+        n, self.nsteps = getattr(self, "nsteps", 0), 0
+        return 0.1, 0.1, n
+
     def evaluate(self, x, y):
         v = _StubTrainer.script[self.epoch]
         self.epoch += 1
@@ -136,6 +144,7 @@ def stub_training(monkeypatch, tmp_path):
     from cellscreen import training
     monkeypatch.setattr(training, "Trainer", _StubTrainer)
     fake_torch = types.SimpleNamespace(
+        cuda=types.SimpleNamespace(is_available=lambda: True),
         device=lambda *a: "dev",
         from_numpy=lambda a: _FakeTensor(a))
     monkeypatch.setitem(sys.modules, "torch", fake_torch)

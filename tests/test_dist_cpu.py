@@ -123,3 +123,95 @@ def test_gradient_allreduce_mean_world2_gloo():
     g0, g1 = _real_gradient(0), _real_gradient(1)
     assert np.abs(g0).max() > 0 and not np.array_equal(g0, g1)
     assert np.array_equal(got, (g0 + g1) / np.float32(2))
+
+
+# ---- data-parallel training loop: the ranks must take every callback decision together ------------------------------
+class _RankTrainer:
+    """Stands in for the GPU trainer in cellscreen.training (as tests/test_callbacks_cpu.py does), with a validation loss that
+    DIFFERS per rank -- what per-rank BatchNormalization moving statistics produce."""
+    script = None
+    rank = 0
+    instances = []
+
+    def __init__(self, init, device_id=0):
+        self.n_trainable, self.n_moving = 4, 2
+        self.epoch, self.lrs, self.moving = 0, [], np.full(2, float(_RankTrainer.rank), np.float32)
+        self.moving_seen_at_eval = []
+        _RankTrainer.instances.append(self)
+
+    def use_grad_tensor(self, t):
+        self.g = t
+
+    def enable_sync_bn(self, dist, rank, world):
+        self.sync = (rank, world)
+
+    def forward_backward(self, x, y):
+        self.g.fill_(1.0 + _RankTrainer.rank)
+        return 0.1 * (1 + _RankTrainer.rank), 0.2
+
+    def apply(self, lr):
+        self.lrs.append(lr)
+        assert float(self.g[0]) == 1.5                 # the mean of the two ranks' gradients
+
+    def evaluate(self, x, y):
+        self.moving_seen_at_eval.append(self.moving.copy())
+        v = _RankTrainer.script[_RankTrainer.rank][self.epoch]
+        self.epoch += 1
+        return v, v
+
+    def export_flat(self):
+        return np.full(4, self.epoch - 1, np.float32), self.moving.copy()
+
+    def load_flat(self, p, m):
+        if m is not None:
+            self.moving = np.asarray(m, np.float32).copy()
+
+    def weights(self):
+        from cellscreen import synth
+        return synth.random_cae(seed=1, trivial_bn=True)
+
+    def close(self):
+        pass
+
+
+def _train_worker(rank, world, port, outdir, q):
+    import torch
+    import torch.distributed as dist
+    from cellscreen import training
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    training.Trainer = _RankTrainer
+    _RankTrainer.rank = rank
+    # rank 0 improves for 4 epochs and then stalls; rank 1's own numbers would keep improving for ever
+    _RankTrainer.script = {0: [1.0, 0.8, 0.6, 0.5] + [0.55] * 40, 1: [1.0 - 0.01 * e for e in range(44)]}
+    t = training.ImprovedAnomalyDetectionTraining(os.path.join(outdir, f"r{rank}"), epochs=40, verbose=0, augment=None, data_parallel=True)
+    _, _, hist = t.train_autoencoder(np.zeros((100, 64, 64), np.float32))
+    tr = _RankTrainer.instances[-1]
+    q.put((rank, hist.stopped_epoch, list(hist.lr_reduced_epochs), hist.history["val_loss"], tr.lrs, [m.tolist() for m in tr.moving_seen_at_eval],
+           getattr(tr, "sync", None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_stop_and_halve_the_rate_together(tmp_path):
+    """World 2 on gloo: scripted val_loss values that diverge between the ranks.  Every rank must act on rank 0's number -- the
+    same stop epoch, the same epochs of learning-rate halving, the same rate at every step -- and validate with ONE set of
+    moving statistics (the mean over the ranks)."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    (_, stop0, red0, val0, lrs0, mov0, sync0), (_, stop1, red1, val1, lrs1, mov1, sync1) = got
+    assert stop0 == stop1 == 13 and red0 == red1 == [8, 13]          # rank 0's script (tests/test_callbacks_cpu.py has the same one)
+    assert val0 == val1 and lrs0 == lrs1 and len(lrs0) == 14 * (80 // 32)
+    assert mov0 == mov1 and mov0[0] == [0.5, 0.5]                       # the mean of the ranks' statistics (0 and 1)
+    assert sync0 == (0, 2) and sync1 == (1, 2)                          # synchronised BatchNormalization is the default

@@ -148,9 +148,10 @@ def test_fp16_split_results_do_not_depend_on_the_batch(weights, det):
         e.close()
 
 
-def test_conv3_winograd_on_bf16_mfmas_is_in_the_fp32_error_class(weights, crops, monkeypatch):
-    """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs on bf16 MFMAs by default (conv3_wino_x3_kernel) and
-    on fp32 MFMAs behind CS_NO_BF16X3_CONV3=1: each against a float64 conv + ReLU + BN + max-pool of the p2 the SAME engine made."""
+def test_conv3_winograd_on_the_16_bit_pipe_is_in_the_fp32_error_class(weights, crops, monkeypatch):
+    """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs as a two-term fp16 split by default
+    (conv3_wino_h2_kernel, 768 MFMAs per cell), as the three-term bf16 split behind CS_NO_FP16X2 (conv3_wino_x3_kernel, 1,536) and on
+    fp32 MFMAs behind CS_NO_BF16X3_CONV3=1: each against a float64 conv + ReLU + BN + max-pool of the p2 the SAME engine made."""
     k = weights.kernels[2].astype(np.float64)
     s = weights.bn_gamma[2].astype(np.float64) / np.sqrt(weights.bn_var[2].astype(np.float64) + weights.bn_eps)
 
@@ -165,11 +166,13 @@ def test_conv3_winograd_on_bf16_mfmas_is_in_the_fp32_error_class(weights, crops,
         ref = a.reshape(len(a), 8, 2, 8, 2, 32).max(axis=(2, 4))
         return H.assert_close_scaled(p3, ref, 3e-6, what), bf16, p3
 
+    eh, bfh, h3 = conv3_error("conv3, Winograd as a two-term fp16 split")
+    monkeypatch.setenv("CS_NO_FP16X2", "1")
     ea, bfa, a3 = conv3_error("conv3, Winograd on bf16 MFMAs")
     monkeypatch.setenv("CS_NO_BF16X3_CONV3", "1")
     eb, bfb, b3 = conv3_error("conv3, Winograd on fp32 MFMAs")
-    assert bfa == 1536 and bfb == 0 and not np.array_equal(a3, b3)
-    print(f"conv3 max err / max|ref|: bf16 MFMAs {ea:.3e}, fp32 MFMAs {eb:.3e}")
+    assert bfh == 768 and bfa == 1536 and bfb == 0 and not np.array_equal(a3, b3) and not np.array_equal(h3, a3)
+    print(f"conv3 max err / max|ref|: fp16 x2 {eh:.3e}, bf16 MFMAs {ea:.3e}, fp32 MFMAs {eb:.3e}")
 
 
 @pytest.mark.parametrize("n", [1, 3, 769, 1537])

@@ -258,6 +258,51 @@ def test_training_class_mirror(tmp_path):
         assert np.array_equal(r[k], r2[k]), k
 
 
+def test_training_class_mirror_on_another_input_shape(tmp_path):
+    """`create_improved_autoencoder(input_shape)` is generic in the reference (CAE_improved_modeltrain.py:184).
+    128 x 128 crops through the class mirror -- the reference's seven convs on the run-time-shaped trainer (csrc/train_generic.hip):
+    two epochs with the reference's augmentation, the reference's files, the detector, and the directory screens 128 x 128 crops with
+    the scores scikit-learn's own objects give."""
+    from cellscreen import model_io
+    from cellscreen.screening import ProductionMutantScreening
+    from cellscreen.training import ImprovedAnomalyDetectionTraining
+    cells = synth.blob_crops(31, 224, hw=(128, 128))
+    out = str(tmp_path / "models128")
+    t = ImprovedAnomalyDetectionTraining(out, epochs=2, verbose=0, detector_fit="sklearn")
+    ae0, enc0 = t.create_improved_autoencoder((128, 128, 1))
+    assert ae0.input_hw == (128, 128) and ae0.channels == spec.CHANNELS and enc0.n_conv == 3
+    autoencoder, encoder, history = t.train_autoencoder(cells)
+    h = history.history
+    assert autoencoder.input_hw == (128, 128) and len(h["loss"]) == 2 and np.isfinite(h["val_loss"]).all() and h["loss"][1] < h["loss"][0]
+    assert model_io.cae_from_keras(os.path.join(out, "final_autoencoder.keras")).input_hw == (128, 128)
+    mse, _ = t.evaluate_reconstruction_quality(autoencoder, cells)
+    assert mse.shape == (224,) and np.isfinite(mse).all()
+    detectors, scaler, pca = t.create_anomaly_detector(encoder, cells)
+    assert scaler.center_.shape == (16 * 16 * 32,)                                   # the 16 x 16 x 32 bottleneck of a 128 x 128 crop
+    s = ProductionMutantScreening(out)
+    assert (s.engine.info.height, s.engine.info.width) == (128, 128)
+    r = s.compute_anomaly_scores(list(cells[:24]))
+    feats = s.engine.encode(cells[:24], which=1)
+    dec = detectors["Conservative"].decision_function(pca.transform(scaler.transform(feats.copy())))
+    assert np.abs(-r["conservative_scores"] - dec).max() <= 1e-4 * np.abs(detectors["Conservative"].dual_coef_).sum()
+    assert np.allclose(r["reconstruction_mse"], mse[:24], rtol=1e-5)
+
+
+def test_trainer_refuses_shapes_its_kernels_would_get_wrong():
+    """the BatchNormalization / pooling kernels the run-time-shaped trainer shares with the reference graph index with
+    shifts and masks (powers of two), and the weight-gradient kernel stages rows in LDS: a 96-row input or a 128-wide 128-channel
+    conv must be refused at cs_train_create, not trained on silently wrong statistics or fail at the first step."""
+    from cellscreen._lib import CellScreenError
+    for hw, channels, n_enc, why in (((96, 128), (8, 16, 32, 32, 16, 8, 1), 3, "powers of two"),
+                                     ((128, 128), (128, 128, 1), 1, "LDS")):
+        w = synth.random_cae(seed=1, hw=hw, channels=channels, n_enc=n_enc, trivial_bn=True)
+        with pytest.raises(CellScreenError) as e:
+            Trainer(w)
+        assert e.value.status == -6 and why in str(e.value), str(e.value)
+    # and a shape that IS accepted trains: gradient parity of such a shape is tests/test_gpu_large_variant.py's
+    Trainer(synth.random_cae(seed=1, hw=(64, 128), channels=(8, 16, 32, 32, 16, 8, 1), trivial_bn=True)).close()
+
+
 def test_create_anomaly_detector_with_the_reference_signature_alone(tmp_path):
     """create_anomaly_detector(encoder, cell_images) (CAE_improved_modeltrain.py:394) on a fresh instance: no training run, no
     autoencoder argument -- the encoder weight set alone is enough to fit and save the detector."""

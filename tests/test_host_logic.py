@@ -129,6 +129,7 @@ class _FakeEngine:
     """Deterministic stand-in for the GPU engine: bookkeeping tests only."""
     class info:
         has_detector = 1
+        height, width = 64, 64
 
     def screen(self, X):
         n = len(X)
