@@ -466,7 +466,8 @@ def main():
 
     # ---- HBM traffic of this tree: PMC child passes first, while this process has not touched the GPU yet
     pmc, pmc_src = None, None
-    if world == 1 and not args.pmc_child and not args.no_pmc:
+    under_profiler = any(k.startswith(("ROCPROFILER_", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not args.pmc_child and not args.no_pmc and not under_profiler:      # never nest profiler runs
         pmc, pmc_src = collect_pmc_traffic(args)
 
     import numpy as np

@@ -6,9 +6,11 @@ BatchNormalization in training mode, MSE loss, backward, Adam -- CAE_improved_mo
 Crops are resident in HBM; the 80/20 split gives 1250 steps per epoch as in the reference.
 
     python bench_train.py [--steps K] [--warmup W] [--batch 32] [--gpus N via torchrun]
-With N > 1 ranks each rank trains on its own batch and the 337 KB gradient is averaged with one
-RCCL all-reduce per step (BatchNormalization statistics stay per-rank, Keras's default under
-data parallelism)."""
+With N > 1 ranks the step is the one cellscreen/training.py ships (ImprovedAnomalyDetectionTraining(data_parallel=True)): ONE
+global batch of --batch cells split over the ranks, BatchNormalization statistics over the whole batch (all-gather of the
+per-rank partials, cs_train_set_sync_bn), the 337 KB gradient averaged with one RCCL all-reduce, no host synchronisation
+beyond what those exchanges need (the wrappers order the library's stream and torch's).  --per-gpu-batch keeps --batch cells
+PER rank instead (global batch N x 32: not the reference's step; labelled so in the line)."""
 import argparse
 import json
 import os
@@ -31,6 +33,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cells", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-gpu-batch", action="store_true", help="N > 1: --batch cells per rank instead of one global batch split over the ranks")
+    ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNormalization statistics")
     ap.add_argument("--variant", action="store_true",
                     help="BASELINE.json configs[4]'s architecture instead: 128x128 crops, filters 32-64-128 | 128-64-32-1 (generic trainer)")
     args = ap.parse_args()
@@ -59,21 +63,26 @@ def main():
     X = X.repeat(reps, 1, 1)[:n_train].contiguous()
     tr = Trainer(synth.random_cae(seed=42, hw=hw, channels=ch, n_enc=n_enc, trivial_bn=True), device_id=local_rank)
     g = torch.zeros(tr.n_trainable, dtype=torch.float32, device=dev)
+    local_b = args.batch
     if world > 1:
         tr.use_grad_tensor(g)
+        if not args.per_gpu_batch:
+            if args.batch % world:
+                sys.exit("--batch %d does not split over %d ranks" % (args.batch, world))
+            local_b = args.batch // world
+        if not args.no_sync_bn and not args.variant:
+            tr.enable_sync_bn(dist, rank, world)
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
 
     def step():
-        idx = torch.randint(0, n_train, (args.batch,), device=dev, generator=gen)
+        idx = torch.randint(0, n_train, (local_b,), device=dev, generator=gen)
         xb = X[idx].contiguous()
         if world > 1:
-            torch.cuda.synchronize()
-            l, _ = tr.forward_backward(xb, xb)
+            l, _ = tr.forward_backward(xb, xb)    # the wrapper orders the library's stream after torch's (the gather above)
             csdist.allreduce_mean_(g)
-            torch.cuda.synchronize()
-            tr.apply(1e-3)
+            tr.apply(1e-3)                        # ... and the update after the all-reduce (Trainer.apply): no host sync of ours
         else:
-            l, _ = tr.step(xb, xb, 1e-3)      # the wrapper orders the library's stream after torch's (cs_train_wait_stream): no host sync needed
+            l, _ = tr.step(xb, xb, 1e-3)
         return l
 
     first = None
@@ -92,14 +101,19 @@ def main():
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t.item())
     if rank == 0:
-        cells = args.steps * args.batch * world
+        cells = args.steps * local_b * world
         line = {"metric": "cells/sec trained (CAE fwd+bwd+Adam, batch 32, fp32)", "value": round(cells / el, 1), "unit": "cells/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak" if (world == 1 or args.per_gpu_batch) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": ("BASELINE.json configs[4] architecture (128x128, filters 32-64-128 | 128-64-32-1): generic trainer, batch %d per GPU" % args.batch)
                                        if args.variant else
-                                       "BASELINE.json configs[1]: CAE training on 50k synthetic 64x64 crops (40k train), batch %d per GPU" % args.batch,
-                           "batch_per_gpu": args.batch, "steps_per_epoch": n_train // args.batch, "parallelism": "dp%d" % world},
+                                       ("BASELINE.json configs[1]: CAE training on 50k synthetic 64x64 crops (40k train), " +
+                                        ("batch %d on one GPU" % args.batch if world == 1 else
+                                         ("global batch %d = %d per GPU x %d (NOT the reference's batch of 32), " % (local_b * world, local_b, world) if args.per_gpu_batch else
+                                          "ONE batch of %d split over %d GPUs (%d cells each, the step training.py ships), " % (args.batch, world, local_b)) +
+                                         ("per-rank BatchNormalization statistics" if args.no_sync_bn or args.variant else "BatchNormalization over the whole batch (all-gathered partials)") +
+                                         ", gradient all-reduce over RCCL")),
+                           "batch_per_gpu": local_b, "global_batch": local_b * world, "steps_per_epoch": n_train // (local_b * world), "parallelism": "dp%d" % world},
                 "tflops_algorithmic": round(cells / el * flop_step / 1e12 / world, 3),
                 "epoch_seconds_at_1250_steps": round(el / args.steps * 1250, 3),
                 "loss_first_last": [round(first, 6), round(last, 6)]}

@@ -3,13 +3,14 @@
 not fit one pass go into separate passes, --kernel-trace only):
 
     rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA \\
-        --output-format csv -d gpurun_out/pmc_sq1 -- python3 bench.py --steps 1 --warmup 0 --cells 131072 --no-cpu-baseline
+        --output-format csv -d gpurun_out/pmc_sq1 -- python3 bench.py --steps 1 --warmup 0 --cells 131072 --no-cpu-baseline --no-pmc --no-extra-legs
     python tools/pmc_sq.py gpurun_out/pmc_sq1 [more pass dirs ...] > profiles/rNN_sq_counters.json
 
 Values are per full-chunk launch, summed over the device.  SQ_INSTS_VALU counts MFMAs too; the derived field
 simd_cycles_mfma_plus_valu = 32 x MFMA + 4 x (VALU - MFMA) is the issue time of the launch if MFMA and VALU
 instructions never overlap (SQ_VALU_MFMA_COEXEC_CYCLES says they do not), and dividing it by the 1,024 SIMDs and the
-launch time gives the clock the chip would need to be fully busy."""
+launch time gives the clock the chip would need to be fully busy.
+--no-pmc keeps bench.py from starting its own rocprofv3 child passes inside the profiled process."""
 import collections
 import csv
 import glob

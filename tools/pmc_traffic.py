@@ -2,9 +2,12 @@
 """Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950:
 MI355X_MICROARCH.md "rocprofv3 PMC slots") into per-kernel HBM traffic per cell.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline --no-pmc --no-extra-legs
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --cells 65536 --chunk 16384 --no-cpu-baseline --no-pmc --no-extra-legs
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 16384 > profiles/rNN_pmc_traffic.json
+
+(--no-pmc --no-extra-legs: bench.py would otherwise start its own rocprofv3 child passes inside the profiled process and run
+its training / raw-crop legs under the profiler.)
 
 Corrections, as the guide prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE
