@@ -36,6 +36,8 @@ struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf c3x3, c4x3, c5x3, c6x3;   // conv3's Winograd U / conv4's / conv5's / conv6's weights as three bf16 planes
     DevBuf c3h2, c4h2, c5h2, c6h2;   // conv3's Winograd U / conv4's / conv5's / conv6's (folded) weights as two fp16 planes (the *_h2 kernels) ...
     float c3h2_inv = 1.0f, c4h2_inv = 1.0f, c5h2_inv = 1.0f, c6h2_inv = 1.0f;   // ... and 1 / their power-of-two scales
+    DevBuf c12w1h2;        // conv1's weights for the fp16 form of the fused kernel's P1, and 1 / their scale
+    float c12w1h2_inv = 1.0f;
     DevBuf c12h2;          // the same U as two fp16 planes (C2H form of the fused kernel) ...
     float c12h2_inv = 1.0f, p1a = 0.0f, p1b = 0.0f;   // ... 1 / their scale, and the bound max|p1| <= p1a max|x| + p1b
     DevBuf c12;            // conv1 + conv2 fused, conv2 as Winograd F(4x4,3x3): transformed-kernel fragments (conv12_fused.hip)
@@ -87,6 +89,7 @@ struct cs_model {
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
     bool h2conv6 = getenv("CS_NO_FP16X2_CONV6") == nullptr; // A/B knob: conv6 (in the fused conv6 + conv7 kernel) alone
+    bool h2conv1 = getenv("CS_NO_FP16X2_CONV1") == nullptr; // conv1 inside the fused conv1 + conv2 kernel alone (needs conv2's)
     bool h2conv3 = getenv("CS_NO_FP16X2_CONV3") == nullptr; // conv3's Winograd contraction alone
     bool h2conv2 = getenv("CS_NO_FP16X2_CONV2") == nullptr; // conv2 inside the fused conv1 + conv2 kernel alone
     bool h2conv4 = getenv("CS_NO_FP16X2_CONV4") == nullptr, h2conv5 = getenv("CS_NO_FP16X2_CONV5") == nullptr;   // conv4 / conv5 alone
@@ -307,6 +310,10 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             rc = upload(set.c12w1x3, wx.data(), wx.size() * sizeof(unsigned int));
             if (rc) return rc;
             pack_conv12_p1_bound(w->kernel[l], ep.data(), &set.p1a, &set.p1b);
+            std::vector<unsigned int> wh(pack_conv12_conv1_h2(nullptr, nullptr, nullptr, nullptr));
+            pack_conv12_conv1_h2(w->kernel[l], ep.data() + cout, wh.data(), &set.c12w1h2_inv);
+            rc = upload(set.c12w1h2, wh.data(), wh.size() * sizeof(unsigned int));
+            if (rc) return rc;
         }
         if (l == 1) {
             tmp.resize(pack_conv12_fragments(nullptr, nullptr, nullptr));
@@ -540,11 +547,12 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
     // conv1 + conv2 as one kernel whenever p1 itself is not asked for (it is never written then)
     const bool fused12 = m->fuse12 && m->use_wino && first == 0 && last >= 1;
     if (fused12) {
-        const bool c1x3 = m->bf16x3 && m->x3conv1, c2h = c1x3 && m->fp16x2 && m->h2conv2;
+        const bool c1x3 = m->bf16x3 && m->x3conv1, c2h = c1x3 && m->fp16x2 && m->h2conv2, c1h = c2h && m->h2conv1;
         LAUNCH(K_CONV12_FUSED, nc,
                launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
                                    m->act[1].as<float>(), nc, m->stream, c1x3 ? set.c12w1x3.as<unsigned int>() : nullptr,
-                                   c2h ? set.c12h2.as<unsigned int>() : nullptr, set.p1a, set.p1b, set.c12h2_inv));
+                                   c2h ? set.c12h2.as<unsigned int>() : nullptr, set.p1a, set.p1b, set.c12h2_inv,
+                                   c1h ? set.c12w1h2.as<unsigned int>() : nullptr, set.c12w1h2_inv));
     }
     if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / A-B knob) needs p1 in HBM
         int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
@@ -1286,7 +1294,8 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
         if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3)      // 16 points x 4 tile groups x 2 slices x 2 blocks x 6 (bf16 split) | 3 (fp16 split)
             v = 16.0 * 4 * 2 * 2 * ((m->fp16x2 && m->h2conv3) ? 3 : 6);
         if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1)               // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs;
-            v = 66 * 8 * 3 + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
+            v = 66 * 8 * ((m->fp16x2 && m->h2conv2 && m->h2conv1) ? 2 : 3)                   // (conv1 as an fp16 split: 2 MFMAs)
+                + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * ((m->fp16x2 && m->h2conv5) ? 3 : 6);   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 | 3 products
         if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6)          // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6 (bf16 split) or 3 (fp16 split)
             v = 4.0 * 16 * 2 * 4 * 2 * ((m->fp16x2 && m->h2conv6) ? 3 : 6);

@@ -52,7 +52,9 @@ size_t pack_wino3_h2(const float* hwio, uint16_t* dst, float* inv_sw);
 // inv_sw = 1 / the scale of ufrag_h2
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
                                int64_t n_cells, hipStream_t stream, const unsigned int* w1x3 = nullptr, const unsigned int* ufrag_h2 = nullptr,
-                               float p1a = 0.0f, float p1b = 0.0f, float inv_sw = 1.0f);
+                               float p1a = 0.0f, float p1b = 0.0f, float inv_sw = 1.0f, const unsigned int* w1h2 = nullptr, float inv_sw1 = 1.0f);
+// w1h2 (optional, with ufrag_h2; pack_conv12_conv1_h2): conv1 too as a two-term fp16 split (two MFMAs per 16 pixels x 16 filters)
+size_t pack_conv12_conv1_h2(const float* hwio, const float* bn_scale, unsigned int* dst, float* inv_sw1);     // returns 32-bit words
 size_t pack_conv12_fragments_h2(const float* hwio, const float* bn_scale, unsigned int* dst, float* inv_sw);     // returns 32-bit words
 void pack_conv12_p1_bound(const float* hwio1, const float* ep1, float* a1, float* b1);
 size_t pack_conv12_conv1_x3(const float* hwio, const float* bn_scale, unsigned int* dst);     // returns 32-bit words

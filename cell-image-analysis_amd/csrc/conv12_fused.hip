@@ -64,6 +64,21 @@ static_assert(LDS_BYTES <= 160 * 1024 && OFF_RING % 16 == 0 && OFF_E2 % 16 == 0 
 __device__ __forceinline__ float vmaxf(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float vminf(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
+// pool_post's maxima are raw inline-asm v_max_f32 (no canonicalisation).  The compiler's hazard recogniser does not look inside
+// inline asm, and the hardware does not interlock a VALU read of a register an MFMA has just written (8-pass XDL write -> VALU
+// read: 11 wait states): an asm v_max placed right behind the MFMA that produces its input reads the OLD register contents
+// -- measured: the last conv row of every P1 batch wrong once nothing else sat between the MFMAs and the pooling.  These fences
+// take the accumulators as read-write operands, so they sit behind the producing MFMAs and ahead of every consumer, and spend
+// the wait states explicitly (16 cycles per batch of 16 MFMAs).
+__device__ __forceinline__ void mfma_result_fence(f32x4& a, f32x4& b)
+{
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void mfma_result_fence(f32x4 (&a)[4], f32x4 (&b)[4])
+{
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+
 // bias -> ReLU -> BN -> 2x2 max of a window of raw conv sums.  The map v -> BN(relu(v + bias)) is monotone with the
 // direction of the BN scale's sign, so the max over the window of the mapped values is the map of the window's max
 // (scale >= 0) or min (scale < 0).  The min case is folded into the weights: channels with a negative BN scale carry
@@ -173,13 +188,14 @@ __device__ __forceinline__ unsigned int c12_absmax8(const f32x4& a, const f32x4&
 // 48 cycles of matrix time per 16 pixels x 16 filters instead of 96, and these MFMAs leave issue slots to the pooling
 // epilogue of the SIMD's other wave.  The records of the rows a group needs are made in P4 of the previous group (the V area
 // is dead from the end of P3 to the start of P2) from the fp32 crop, which stays for the ninth tap.
-template <bool DIAG, bool C1X3, bool C2H>
+template <bool DIAG, bool C1X3, bool C2H, bool C1H = false>
 __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1frag,
                                                               const float* __restrict__ ep1, const float* __restrict__ ufrag,
                                                               const float* __restrict__ ep2, float* __restrict__ p2, long n_cells,
                                                               unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3,
-                                                              float p1a, float p1b, float inv_sw)
+                                                              float p1a, float p1b, float inv_sw, float inv_sw1)
 {
+    static_assert(!C1H || (C1X3 && C2H), "conv1 as an fp16 split rides on the scale plumbing of C2H and the record slots of C1X3");
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ring = (float*)(smem + OFF_RING);
@@ -214,7 +230,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         const float sc = ep2[64 + c];
         ((f32x4*)(smem + OFF_EP2))[c] = f32x4{ep2[c], sc, ep2[128 + c], sc >= 0.0f ? 1.0f : -1.0f};
     }
-    if constexpr (C1X3) {
+    if constexpr (C1H) {
+        for (int i = tid; i < (2 * 2 * 64 * 16) / 4; i += NTHR) ((unsigned int*)(smem + OFF_B1X))[i] = w1x3[i];
+    } else if constexpr (C1X3) {
         for (int i = tid; i < (2 * 3 * 64 * 16 + 32 * 4) / 4; i += NTHR) ((unsigned int*)(smem + OFF_B1X))[i] = w1x3[i];
     }
     {
@@ -231,9 +249,16 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
     }
     __syncthreads();
     // C2H: the scale of this cell's V (a wave-uniform power of two, kept in scalar registers) and what undoes it and the weights'
-    float vscale = 1.0f, vunscale = 1.0f;
+    float vscale = 1.0f, vunscale = 1.0f, xscale = 1.0f, xunscale = 1.0f;      // xscale: C1H, puts max|x| of the crop into [2^14, 2^15)
     auto set_scale = [&]() {
         const float xm = __builtin_bit_cast(float, *(const unsigned int*)(smem + OFF_XMAX));
+        if constexpr (C1H) {
+            int Ex = (int)((__builtin_bit_cast(unsigned int, xm) >> 23) & 0xffu);
+            Ex = Ex < 40 ? 40 : (Ex > 254 ? 254 : Ex);
+            Ex = __builtin_amdgcn_readfirstlane(Ex);
+            xscale = __builtin_bit_cast(float, (unsigned int)(268 - Ex) << 23);
+            xunscale = __builtin_bit_cast(float, (unsigned int)(Ex - 14) << 23) * inv_sw1;
+        }
         const float vb = 100.0f * fmaf(p1a, xm, p1b);                       // >= every |V| of the cell
         int E = (int)((__builtin_bit_cast(unsigned int, vb) >> 23) & 0xffu);
         E = E < 40 ? 40 : (E > 254 ? 254 : E);
@@ -250,6 +275,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         // 1,152 .. 1,440 records: two per thread and a third for some; all reads first (one LDS latency instead of three)
         const float* src = inp + row0 * INP_STRIDE;
         const float v0 = src[t], v1 = src[t + NTHR], v2 = src[t + 2 * NTHR < nrec ? t + 2 * NTHR : t];
+        if constexpr (C1H) {       // one dword per pixel: [fp16(S x) | fp16(S x - hi)]
+            auto rec = [&](float x) {
+                const float v = x * xscale;
+                const float rr = v - (float)(_Float16)v;
+                return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v, rr}, f16x2));
+            };
+            *(unsigned int*)(smem + t * 4) = rec(v0);
+            *(unsigned int*)(smem + (t + NTHR) * 4) = rec(v1);
+            if (t + 2 * NTHR < nrec) *(unsigned int*)(smem + (t + 2 * NTHR) * 4) = rec(v2);
+            return;
+        }
         *(u32x2*)(smem + t * 8) = c1_record(v0);
         *(u32x2*)(smem + (t + NTHR) * 8) = c1_record(v1);
         if (t + 2 * NTHR < nrec) *(u32x2*)(smem + (t + 2 * NTHR) * 8) = c1_record(v2);
@@ -280,7 +316,63 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 stg0 = *(const f32x4*)src;
                 stg1 = *(const f32x4*)(src + 32 * 64);
             }
-            if constexpr (C1X3) {
+            if constexpr (C1H) {
+                // conv1 as a two-term fp16 split.  A pixel's record is ONE dword [hi | lo]; a lane's K = 8 slots are the records at
+                // offsets {0, 1, 72, 73} (two columns x two rows) from a per-kq base {0, 2, 144, 146} of its pixel's window: kq 0 gets
+                // taps (0,0) (0,1) (1,0) (1,1), kq 1 (0,2) (1,2), kq 2 (2,0) (2,1), kq 3 (2,2); the other slots read neighbouring
+                // records (finite) against zero weights.  Two MFMAs: B = [w_hi, 0] per tap gives hi w_hi, B = [w_lo, w_hi] gives
+                // hi w_lo + lo w_hi -- all nine taps in one K = 32 instruction, no separate ninth tap.
+                const int kb = (kq2 & 1) * 2 + (kq2 >> 1) * (2 * INP_STRIDE);
+                const int offR = (kb + 16 * xt + li2 + 3) * 4;
+                const f16x8 Bh = *(const f16x8*)(smem + OFF_B1X + ((s1 * 2 + 0) * 64 + l2) * 16);
+                const f16x8 Bx = *(const f16x8*)(smem + OFF_B1X + ((s1 * 2 + 1) * 64 + l2) * 16);
+                const int c1 = s1 * 16 + li2;
+                f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);                 // bias, bn scale, bn shift, sign
+                e1v[1] *= vscale; e1v[2] *= vscale;                                     // the ring holds S p1
+                e1v[3] *= xunscale;                                                     // the sums carry S_x S_w1
+                const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
+                const int row0 = g == 0 ? 0 : 16 * g + 2;                                // first INP row of this group's records
+                auto frag = [&](int inp_row) -> f16x8 {
+                    const unsigned int* b = (const unsigned int*)(smem + (inp_row - row0) * (INP_STRIDE * 4) + offR);
+                    return __builtin_bit_cast(f16x8, u32x4{b[0], b[1], b[INP_STRIDE], b[INP_STRIDE + 1]});
+                };
+                auto conv_row = [&](const f16x8& a) -> f32x4 {
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bx, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bh, acc, 0, 0, 0);
+                };
+                auto p1_rows4 = [&](int qb, bool last_is_zero_row) {
+                    f16x8 a0[4], a1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = (i == 3 && last_is_zero_row) ? qb + 2 : qb + i;        // a valid row; its result is discarded
+                        a0[i] = frag(2 * (q - 1));
+                        a1[i] = frag(2 * (q - 1) + 1);
+                    }
+                    f32x4 acc0[4], acc1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc0[i] = conv_row(a0[i]); acc1[i] = conv_row(a1[i]); }
+                    mfma_result_fence(acc0, acc1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
+                        float v0 = pool_post(acc0[i][0], acc0[i][1], acc1[i][0], acc1[i][1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        float v1 = pool_post(acc0[i][2], acc0[i][3], acc1[i][2], acc1[i][3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                        if (i == 3 && last_is_zero_row) v0 = v1 = 0.0f;                     // q = 33: the bottom zero row
+                        row[0] = v0;
+                        row[32] = v1;
+                    }
+                };
+                if (g == 0) {
+                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
+                    f32x4 acc0 = conv_row(frag(0)), acc1 = conv_row(frag(1));                     // q = 1: conv rows 0, 1
+                    mfma_result_fence(acc0, acc1);
+                    float* const row = ring + RING_ROWF + pwoff;
+                    row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
+                    row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
+                }
+                p1_rows4(8 * g + 2, false);
+                p1_rows4(8 * g + 6, g == 3);
+            } else if constexpr (C1X3) {
                 // A fragment of lane (pixel li, kq): the records of taps 2 kq and 2 kq + 1 (tap t = (t / 3, t % 3)) of its pixel
                 const int tA = 2 * kq2, tB = 2 * kq2 + 1;
                 const int offA = ((tA / 3) * INP_STRIDE + (tA % 3) + 16 * xt + li2 + 3) * 8;
@@ -326,7 +418,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { acc0[i] = conv_row(a0[i]); acc1[i] = conv_row(a1[i]); }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { tap9(acc0[i], rr[i]); tap9(acc1[i], rr[i] + 1); }
+                    for (int i = 0; i < 4; ++i) { tap9(acc0[i], rr[i]); tap9(acc1[i], rr[i] + 1); }     // compiler-visible fmas on every accumulator: they carry the wait states
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
@@ -391,6 +483,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                             acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][s], B1[s], acc0[i], 0, 0, 0);
                             acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], B1[s], acc1[i], 0, 0, 0);
                         }
+                    mfma_result_fence(acc0, acc1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
@@ -412,6 +505,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[toff[s]], B1[s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[toff[s] + INP_STRIDE], B1[s], acc1, 0, 0, 0);
                     }
+                    mfma_result_fence(acc0, acc1);
                     float* const row = ring + RING_ROWF + pwoff;
                     row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
                     row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
@@ -610,11 +704,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 };
                 if (gcol == 0) finish(std::true_type{});
                 else finish(std::false_type{});
+                if constexpr (C2H) {
+                    if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2 (this group's sums are out)
+                }
                 if constexpr (C1X3) {      // V is dead until the next P2: the next group's records (g = 3: the next cell's crop is in place since P2)
                     if (g < 3 || has_next) build_records(g < 3 ? g + 1 : 0, t2);
-                }
-                if constexpr (C2H) {
-                    if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2
                 }
             }
             C12_STAMP(6)
@@ -770,12 +864,41 @@ size_t pack_conv12_conv1_x3(const float* hwio /* [3][3][1][32] */, const float* 
     return total;
 }
 
+// conv1 for the fp16 form of P1 (C1H): per (slice, MFMA m, lane (li, kq)) eight fp16 = the B slots (pair p, plane) of the lane's four
+// record positions {0, 1, 72, 73} from its base {0, 2, 144, 146}[kq]: the taps of conv12_fused_kernel's comment, zero elsewhere.
+// m = 0: [w_hi, 0] per tap, m = 1: [w_lo, w_hi]; w scaled by S_w1 (a power of two), negated for filters with a negative BN scale.
+size_t pack_conv12_conv1_h2(const float* hwio /* [3][3][1][32] */, const float* bn_scale /* [32] */, unsigned int* dst, float* inv_sw1)
+{
+    const size_t total = (size_t)(2 * 2 * 64 * 16) / 4;
+    if (!dst) return total;
+    const float S = f16x2_weight_scale(hwio, 9 * 32);
+    if (inv_sw1) *inv_sw1 = 1.0f / S;
+    unsigned short* d16 = (unsigned short*)dst;
+    for (int nsl = 0; nsl < 2; ++nsl)
+        for (int m = 0; m < 2; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int li = lane & 15, kq = lane >> 4, p = j >> 1, plane = j & 1, co = nsl * 16 + li;
+                    const int dy = (kq >> 1) * 2 + (p >> 1), dx = (kq & 1) * 2 + (p & 1);       // window position of slot pair p
+                    unsigned short v = 0;
+                    if (dy < 3 && dx < 3) {
+                        float w = hwio[(size_t)(dy * 3 + dx) * 32 + co];
+                        if (bn_scale[co] < 0.0f) w = -w;
+                        uint16_t hi, lo;
+                        f16x2_split(w, S, hi, lo);
+                        v = m == 0 ? (plane == 0 ? hi : 0) : (plane == 0 ? lo : hi);
+                    }
+                    d16[(((size_t)nsl * 2 + m) * 64 + lane) * 8 + j] = v;
+                }
+    return total;
+}
+
 unsigned long long* g_c12_diag = nullptr;
 int g_c12_diag_blocks = 0;
 
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
                                int64_t n_cells, hipStream_t stream, const unsigned int* w1x3, const unsigned int* ufrag_h2, float p1a, float p1b,
-                               float inv_sw)
+                               float inv_sw, const unsigned int* w1h2, float inv_sw1)
 {
     static int cus = 0;
     static const bool diag = getenv("CS_C12_DIAG") != nullptr;
@@ -786,6 +909,8 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
         C12_ATTR(false, false, false); C12_ATTR(true, false, false); C12_ATTR(false, true, false); C12_ATTR(true, true, false);
         C12_ATTR(false, true, true); C12_ATTR(true, true, true);
 #undef C12_ATTR
+        if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e;
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -800,8 +925,15 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
     unsigned long long* const dp = diag ? g_c12_diag : nullptr;
 #define C12_GO(D, X, H, UF)                                                                                                         \
     hipLaunchKernelGGL((conv12_fused_kernel<D, X, H>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, UF, ep2, p2,      \
-                       (long)n_cells, dp, w1x3, p1a, p1b, inv_sw)
-    if (w1x3 && ufrag_h2) { if (diag) C12_GO(true, true, true, (const float*)ufrag_h2); else C12_GO(false, true, true, (const float*)ufrag_h2); }   // conv2 as an fp16 split
+                       (long)n_cells, dp, w1x3, p1a, p1b, inv_sw, 1.0f)
+    if (w1h2 && ufrag_h2) {      // conv1 and conv2 as fp16 splits
+        if (diag)
+            hipLaunchKernelGGL((conv12_fused_kernel<true, true, true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1,
+                               (const float*)ufrag_h2, ep2, p2, (long)n_cells, dp, w1h2, p1a, p1b, inv_sw, inv_sw1);
+        else
+            hipLaunchKernelGGL((conv12_fused_kernel<false, true, true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1,
+                               (const float*)ufrag_h2, ep2, p2, (long)n_cells, dp, w1h2, p1a, p1b, inv_sw, inv_sw1);
+    } else if (w1x3 && ufrag_h2) { if (diag) C12_GO(true, true, true, (const float*)ufrag_h2); else C12_GO(false, true, true, (const float*)ufrag_h2); }   // conv2 as an fp16 split
     else if (w1x3) { if (diag) C12_GO(true, true, false, ufrag); else C12_GO(false, true, false, ufrag); }       // conv1 on bf16 MFMAs
     else           { if (diag) C12_GO(true, false, false, ufrag); else C12_GO(false, false, false, ufrag); }
 #undef C12_GO

@@ -256,7 +256,14 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         };
         // pooled store of a tile pair (rows y, y+1; the lane holds pixels x..x+3 of both): two outputs at o, o + COUT
         // (the wave-uniform all_up test is a template argument so that an unrolled caller can hoist it out of its loop)
-        auto pooled_store_t = [&](auto allup_c, const f32x4& acc0, const f32x4& acc1, float* o) {
+        auto pooled_store_t = [&](auto allup_c, const f32x4& acc0_in, const f32x4& acc1_in, float* o) {
+            // The maxima below are inline-asm v_max / v_min: the compiler's hazard recogniser does not look inside inline asm and
+            // the hardware does not interlock a VALU read of a register an MFMA has just written (8-pass XDL write -> VALU read:
+            // 11 wait states).  conv12_fused.hip measured what that costs -- stale accumulators in the pooled maximum whenever the asm
+            // lands right behind the last MFMA.  The fence takes the accumulators as read-write operands (so it sits behind the
+            // producing MFMAs and ahead of every consumer) and spends the wait states.
+            f32x4 acc0 = acc0_in, acc1 = acc1_in;
+            if constexpr (C::EPI != EPI_SUMPOOL) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
             if constexpr (C::EPI == EPI_SUMPOOL) {
                 o[0] = (acc0[0] + acc0[1]) + (acc1[0] + acc1[1]);
                 o[C::COUT] = (acc0[2] + acc0[3]) + (acc1[2] + acc1[3]);

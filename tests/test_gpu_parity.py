@@ -513,8 +513,9 @@ def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
         p2 = e.layer_output(x, 1)
         p2_two = e2.layer_output(x, 1)
         p2_c1f32 = e3.layer_output(x, 1)
-        # conv1: 1,584 bf16 MFMAs per cell; conv2 as a two-term fp16 split: 36 points x 4 tile groups x 4 slices x 3 products = 1,728 more
-        assert e.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 1584 + 1728 and e.profile()["conv1_conv2_fused"]["mfma_per_cell"] == 0
+        # conv1 as a two-term fp16 split: 66 conv rows x 8 (x-tile, slice) x 2 MFMAs = 1,056 16-bit MFMAs per cell (1,584 as three bf16
+        # ones); conv2 likewise: 36 points x 4 tile groups x 4 slices x 3 products = 1,728 more
+        assert e.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 1056 + 1728 and e.profile()["conv1_conv2_fused"]["mfma_per_cell"] == 0
         assert e3.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 0 and e3.profile()["conv1_conv2_fused"]["mfma_per_cell"] > 4608
     finally:
         e.close(); e2.close(); e3.close()
