@@ -52,6 +52,11 @@
  *     np.expand_dims at improved_detection.py:122 adds it); conv kernels HWIO
  *     [3][3][cin][cout] as Keras stores them; features [n][h*w*c] in (h,w,c) order
  *     as the reshape at improved_detection.py:131 produces.
+ *   - The library links no communication library.  Multi-GPU is one process and one handle per GPU; every
+ *     exchange between processes (the gradient all-reduce, the all-gather of BatchNormalization partials,
+ *     the gather of results) happens ABOVE this ABI, in the host's own communicator (RCCL through
+ *     torch.distributed in cellscreen/dist.py), on buffers the caller owns: cs_train_set_grad_buffer and
+ *     cs_train_set_sync_bn are the two hooks.  Screening has no exchange on its data path.
  *   - There is NO CPU fallback: without a gfx950 device every compute entry point
  *     returns CS_ERR_NO_DEVICE.
  */
