@@ -50,8 +50,11 @@ import time
 # HIP deals its streams round-robin onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share one run
 # their work in submission order.  This process has more than four (torch's, each handle's compute and copy streams, the
 # e2e leg's upload stream): measured on the e2e_raw leg, the upload of chunk i + 1 and the preprocess kernel of chunk i
-# landed on one queue and ran one after the other (2.1 M cells/s; 3.1 M with 8 queues).  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# landed on one queue and ran one after the other (2.1 M cells/s at 4 queues; 3.0 M at 5, 6, 7 or 8).  More is not better:
+# from 7 queues on, the training step that runs later in the same process -- ~75 small kernels on two streams with 14
+# cross-stream events -- takes 1.05 ms instead of 0.67 (tools/scratch/train_probe3.py: the command processor then
+# time-slices its queues and every cross-queue dependency waits for a slice).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "cell-image-analysis_amd"), os.path.join(ROOT, "tools"), ROOT):
@@ -325,6 +328,7 @@ def train_leg(steps, local_rank, seed):
         for i in range(steps):
             yb = Xtr[perm[i]].contiguous()                 # the wrapper orders the library's stream after torch's
             tr.step_async(tr.augment(yb, gen.random_transforms(32, (64, 64), rng)), yb, 1e-3)
+        t_enq = time.perf_counter() - t0                   # when the host has enqueued the epoch (it runs ahead of the device, or bounds it)
         loss_epoch, mae_epoch, _ = tr.read_metrics()       # one host round trip for the epoch (Keras's running means)
         torch.cuda.synchronize()
         t_train = time.perf_counter() - t0
@@ -335,7 +339,7 @@ def train_leg(steps, local_rank, seed):
         tr.close()
     return dict(workload="BASELINE.json configs[1]: CAE training (fwd + bwd + Adam, BN batch statistics, on-device augmentation of the input), "
                          "50,000 synthetic crops -> 40,000 / 10,000, batch 32, fp32, 1 GPU" + ("" if full_epoch else " (--train-steps: partial epoch, no validation pass)"),
-                steps=steps, ms_per_step=round(t_train / steps * 1e3, 4), cells_per_s=round(steps * 32 / t_train, 1),
+                steps=steps, ms_per_step=round(t_train / steps * 1e3, 4), host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 4), cells_per_s=round(steps * 32 / t_train, 1),
                 tflops_algorithmic=round(steps * 32 / t_train * 3 * FLOP_PER_CELL / 1e12, 3),
                 epoch_s=round(el, 3) if full_epoch else None, validation_s=round(el - t_train, 3) if full_epoch else None,
                 loss_first_step=round(first, 6), loss_epoch_mean=round(loss_epoch, 6), mae_epoch_mean=round(mae_epoch, 6),
