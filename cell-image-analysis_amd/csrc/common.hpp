@@ -10,6 +10,61 @@ namespace cs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- the two-term fp16 split x S = hi + lo on the mixed-precision fma ------------------------------------------
+// hi = fp16(x S) and lo = fp16(x S - hi) are ONE v_fma_mix*_f16 each (the product with a power of two and the residual are
+// exact in fp32, so the instruction's single rounding is the conversion's): 2 VALU per value where scale / convert / convert
+// back / subtract / convert took 3 to 4.  tools/microbench/fp16_split_probe.hip: bit-identical on 16.7 M values x 3 scales,
+// except that fma(-0, S, +0) is +0 where the conversion kept -0.
+// The instructions sit in inline asm (there is no builtin), and the hazard recogniser does not look inside: ordinary VALU
+// consumers are interlocked by the hardware, but a DPP / MFMA read of a result needs two wait states.  Used where the split
+// is a phase of its own (conv12_fused.hip: P2 3.6 k -> 3.0 k cycles per group, the kernel 83.2 -> 79.5 ms per 1 M cells).  In
+// the kernels that split while staging under MFMAs (conv3, conv4, conv5, conv6) the same helpers measured SLOWER on the same
+// box (conv3 24.2 -> 25.2 ms, conv5 15.6 -> 16.4): opaque asm blocks cost the compiler more scheduling freedom than the saved
+// instructions return; those keep the convert / subtract form.
+// One value -> the dword [fp16(x S) | fp16(x S - hi)] (conv1's crop records).
+__device__ __forceinline__ unsigned int f16x2_split_word_scaled(float x, float S)
+{
+    unsigned int pk;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+        : "=&v"(pk) : "v"(x), "v"(S));
+    return pk;
+}
+// Six values, already scaled -> six dwords for conv2's V (conv12_fused.hip, P2): [hi | lo] of each value, exchanged with the
+// neighbouring lane (quad_perm [1,0,3,2]) and merged by `sel` (even lane [hi c | hi c+1], odd lane [lo c-1 | lo c]).  The DPP
+// read of a VALU result needs two wait states: the six independent chains are interleaved so that five instructions separate them.
+__device__ __forceinline__ void f16x2_split6_exchange(const float (&v)[6], unsigned int sel, unsigned int (&out)[6])
+{
+    unsigned int p0, p1, p2, p3, p4, p5;
+    asm("v_cvt_f16_f32 %6, %12\n\t"
+        "v_cvt_f16_f32 %7, %13\n\t"
+        "v_cvt_f16_f32 %8, %14\n\t"
+        "v_cvt_f16_f32 %9, %15\n\t"
+        "v_cvt_f16_f32 %10, %16\n\t"
+        "v_cvt_f16_f32 %11, %17\n\t"
+        "v_fma_mixhi_f16 %6, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %7, %7, -1.0, %13 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %8, %8, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %9, %9, -1.0, %15 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %10, %10, -1.0, %16 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %11, %11, -1.0, %17 op_sel_hi:[1,0,0]\n\t"
+        "v_mov_b32_dpp %0, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %4, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %5, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_perm_b32 %0, %0, %6, %18\n\t"
+        "v_perm_b32 %1, %1, %7, %18\n\t"
+        "v_perm_b32 %2, %2, %8, %18\n\t"
+        "v_perm_b32 %3, %3, %9, %18\n\t"
+        "v_perm_b32 %4, %4, %10, %18\n\t"
+        "v_perm_b32 %5, %5, %11, %18"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]),
+          "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(sel));
+}
+
 // Geometry of one conv layer of the reference graph (CAE_improved_modeltrain.py:191-216)
 // as the kernels see it.  H, W: conv grid (= conv output, pre-pool) size.
 struct LayerGeom {

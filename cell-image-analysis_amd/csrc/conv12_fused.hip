@@ -277,9 +277,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         const float v0 = src[t], v1 = src[t + NTHR], v2 = src[t + 2 * NTHR < nrec ? t + 2 * NTHR : t];
         if constexpr (C1H) {       // one dword per pixel: [fp16(S x) | fp16(S x - hi)]
             auto rec = [&](float x) {
-                const float v = x * xscale;
-                const float rr = v - (float)(_Float16)v;
-                return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v, rr}, f16x2));
+                return f16x2_split_word_scaled(x, xscale);
             };
             *(unsigned int*)(smem + t * 4) = rec(v0);
             *(unsigned int*)(smem + (t + NTHR) * 4) = rec(v1);
@@ -563,19 +561,15 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     for (int r = 0; r < 6; ++r) {
                         float o[6];
                         bt6(t[r], o);
+                        // [hi | lo] of each value (hi = fp16(v), lo = fp16(v - hi): one v_cvt + one v_fma_mixhi_f16), the dword of
+                        // lane ^ 1 by DPP, one v_perm_b32: 4 VALU per value, six chains interleaved (common.hpp).  Both hi are
+                        // fp16 of the SAME fp32 v -- left to the compiler, the transform's last fma was folded into one of the
+                        // two conversions (v_fma_mixlo_f16: one rounding of the exact sum) and the residual was taken against the
+                        // wrong hi (2^-10 errors in p2).
+                        unsigned int pk[6];
+                        f16x2_split6_exchange(o, sel, pk);
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            float v = o[c];
-                            // v is the fp32 result of the transform's last fma.  Left visible, the compiler folds that fma into the
-                            // conversion below (v_fma_mixlo_f16: ONE rounding of the exact sum to fp16) while the pack further
-                            // down converts the fp32-rounded v: two different hi values whenever the double rounding matters,
-                            // i.e. a residual taken against the wrong hi -- measured as 2^-10 errors in p2.  Laundered, both are fp16(v).
-                            asm volatile("" : "+v"(v));
-                            const float rr = v - (float)(_Float16)v;                                        // exact in fp32
-                            const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{v, rr}, f16x2));   // [hi | lo]
-                            const unsigned int ot = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)pk, 0xB1, 0xF, 0xF, true);      // lane ^ 1
-                            *(unsigned int*)(smem + (r * 6 + c) * 2048 + hoff) = __builtin_amdgcn_perm(ot, pk, sel);
-                        }
+                        for (int c = 0; c < 6; ++c) *(unsigned int*)(smem + (r * 6 + c) * 2048 + hoff) = pk[c];
                     }
                 } else {
 #pragma unroll
