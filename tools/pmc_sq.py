@@ -25,7 +25,8 @@ N_SIMD = 256 * 4
 
 def main():
     out = collections.defaultdict(dict)
-    x3 = set()      # families whose main contraction ran as v_mfma_f32_16x16x32_bf16 (16 cycles each, VALU may issue beside them)
+    x3 = set()      # families whose main contraction ran as v_mfma_f32_16x16x32_{bf16,f16} (16 cycles each, VALU may issue beside them)
+    all16 = set()
     for d in sys.argv[1:]:
         # the newest pass if the directory was reused
         rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime))))
@@ -36,8 +37,10 @@ def main():
             for k, counters in by.items():
                 if pat not in k:
                     continue
-                if "x3_kernel" in pat or ("conv12_fused_kernel" in pat and ", true>" in k):
-                    x3.add(name)      # conv12_fused_kernel<DIAG, C1X3 = true>: conv1 on bf16 MFMAs
+                if "x3_kernel" in pat or "_h2_kernel" in pat or ("conv12_fused_kernel" in pat and ", true" in k):
+                    x3.add(name)      # 16-bit MFMAs (bf16 or fp16 split); conv12_fused_kernel<DIAG, C1X3 = true, ...>: conv1 on them
+                if "conv12_fused_kernel" in pat and "true, true, true>" in k:
+                    all16.add(name)   # <DIAG, C1X3, C2H, C1H>: conv2 as an fp16 split too -- no fp32 MFMA left in the kernel
                 for c, v in counters.items():
                     longest = max(x[1] for x in v)
                     full = [x for x in v if x[1] > 0.7 * longest]
@@ -47,9 +50,9 @@ def main():
         if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c:
             if name in x3:
                 # bf16 MFMAs: 16 cycles each; the two fused kernels also issue fp32 MFMAs (32 cycles): conv7's contraction / conv2
-                per_cell_f32 = {"conv6_conv7_fused_err": 512, "conv1_conv2_fused": 4608}.get(name, 0)
+                per_cell_f32 = 0 if name in all16 else {"conv6_conv7_fused_err": 512, "conv1_conv2_fused": 4608}.get(name, 0)
                 f32 = per_cell_f32 * 65536
-                c["mfma_kind"] = "v_mfma_f32_16x16x32_bf16" + (" + %d v_mfma_f32_16x16x4_f32 per cell" % per_cell_f32 if f32 else "")
+                c["mfma_kind"] = "v_mfma_f32_16x16x32_{bf16,f16}" + (" + %d v_mfma_f32_16x16x4_f32 per cell" % per_cell_f32 if f32 else "")
                 c["simd_cycles_mfma"] = 16 * (c["SQ_INSTS_MFMA"] - f32) + 32 * f32
                 c["mfma_util_at_2p1_ghz"] = round(c["simd_cycles_mfma"] / N_SIMD / (c["launch_ms_under_pmc"] * 1e-3 * 2.1e9), 3)
                 continue
