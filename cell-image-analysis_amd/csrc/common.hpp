@@ -158,6 +158,10 @@ void f16x2_split(float w, float S, uint16_t& hi, uint16_t& lo);
 // b7_dev: device, the conv's bias; errpart: [n][4][2]; recon (may be null): [n][64][64].
 hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,
                             float* errpart, float* recon, int64_t n_cells, hipStream_t stream);
+// the training step's form: also dz = dL/dz of the sigmoid conv for L = mean((out - x)^2) over n*64*64 elements, and its sum per
+// (cell, strip) in dzsum_part [n][4] (the bias gradient's partial sums) -- what loss_dz_kernel computed from a stored reconstruction
+hipError_t launch_conv7_err_train(const float* a6, const float* x, const float* weff_dev, const float* b7_dev, float* errpart,
+                                  float* recon, float* dz, float* dzsum_part, int64_t n_cells, hipStream_t stream);
 void conv7_effective_weights(const float* w7_hwio, float* weff);
 
 // ---- training (train.hip, conv_mfma.hip) -----------------------------------------------
@@ -188,7 +192,9 @@ hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats,
                             int* Gz, hipStream_t s);
 hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* part, int64_t n_cells, int* nparts,
                         hipStream_t s);
-hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s);
+// errpart / nparts / nelem / out2 (optional): thread 0 also reduces the forward pass's error partial sums to {loss, mae}
+hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s,
+                             const float* errpart = nullptr, long nparts = 0, long nelem = 0, float* out2 = nullptr);
 // alpha_dev == NULL: the step size is alpha_val; macc (optional): {sum loss, sum mae, batches} += batch_scal's {loss, mae}, 1
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, const float* alpha_dev, float b1, float b2, float eps,
                        hipStream_t s, float alpha_val = 0.0f, const float* batch_scal = nullptr, double* macc = nullptr);

@@ -25,13 +25,15 @@ constexpr int C7_LDS = C7_R * C7_WP * C7_PS * 4;
 constexpr int C7_NSTRIP = C7_HS / C7_SR;     // 4 partial sums per cell
 
 
+template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
     const float* __restrict__ a6, const float* __restrict__ x, const float* __restrict__ weff /*[16][32]*/,
-    const float* __restrict__ b7p, float* __restrict__ errpart, float* __restrict__ recon, long n_cells)
+    const float* __restrict__ b7p, float* __restrict__ errpart, float* __restrict__ recon, long n_cells,
+    float* __restrict__ dz, float* __restrict__ dzsum_part)
 {
     const float b7 = b7p[0];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float (*red)[4] = (float (*)[4])(smem + C7_LDS);  // 2 x 4 wave sums, after the strip
+    float (*red)[4] = (float (*)[4])(smem + C7_LDS);  // 2 (3: TRAIN) x 4 wave sums, after the strip
     const int tid = threadIdx.x;
     const long total = n_cells * C7_NSTRIP;
     // The kernel is HBM-bound (it streams a6 once, 172 KB/cell with the row halo), so the strip of
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
         }
 
         // sigmoid, error terms
-        float s2 = 0.0f, s1 = 0.0f;
+        float s2 = 0.0f, s1 = 0.0f, sz = 0.0f;
+        const float kz = 2.0f / (float)(n_cells * 64 * 64);        // TRAIN: d mean((out - x)^2) / d out
         const int Y = 2 * (y0 + ly), X = 2 * lx;
         const float* xc = x + (size_t)cell * 64 * 64;
 #pragma unroll
@@ -111,22 +114,30 @@ __global__ __launch_bounds__(256, 2) void conv7_err_kernel(
             for (int b = 0; b < 2; ++b) {
                 const float v = acc[a][b] + b7;
                 const float r = 1.0f / (1.0f + expf(-v));
-                const float d = xc[(Y + a) * 64 + X + b] - r;
+                const float xv = xc[(Y + a) * 64 + X + b];
+                const float d = xv - r;
                 s2 = fmaf(d, d, s2);
                 s1 += fabsf(d);
                 if (recon) recon[(size_t)cell * 64 * 64 + (Y + a) * 64 + X + b] = r;
+                if constexpr (TRAIN) {
+                    const float g = kz * (r - xv) * r * (1.0f - r);     // loss_dz_kernel's expression
+                    dz[(size_t)cell * 64 * 64 + (Y + a) * 64 + X + b] = g;
+                    sz += g;
+                }
             }
         // deterministic block reduction: wave shuffle tree, then 4 wave sums in order
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             s2 += __shfl_down(s2, off, 64);
             s1 += __shfl_down(s1, off, 64);
+            if constexpr (TRAIN) sz += __shfl_down(sz, off, 64);
         }
-        if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = s1; }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = s2; red[1][tid >> 6] = s1; if constexpr (TRAIN) red[2][tid >> 6] = sz; }
         __syncthreads();
         if (tid == 0) {
             errpart[(cell * C7_NSTRIP + strip) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
             errpart[(cell * C7_NSTRIP + strip) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+            if constexpr (TRAIN) dzsum_part[cell * C7_NSTRIP + strip] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
         }
         __syncthreads();
     }
@@ -151,18 +162,19 @@ void conv7_effective_weights(const float* w7_hwio, float* weff /*[16][32]*/)
                     }
 }
 
-hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,
-                            float* errpart, float* recon, int64_t n_cells, hipStream_t stream)
+template <bool TRAIN>
+static hipError_t launch_conv7_err_t(const float* a6, const float* x, const float* weff_dev, const float* b7_dev, float* errpart,
+                                     float* recon, float* dz, float* dzsum_part, int64_t n_cells, hipStream_t stream)
 {
+    constexpr int LDS = C7_LDS + 48;
     static int resident = 0;   // persistent grid = what the chip holds at once (see conv_mfma.hip)
     if (!resident) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv7_err_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C7_LDS + 32);
+        hipError_t e = hipFuncSetAttribute((const void*)conv7_err_kernel<TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv7_err_kernel, 256, C7_LDS + 32);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv7_err_kernel<TRAIN>, 256, LDS);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
@@ -170,9 +182,21 @@ hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_d
     const long total = (long)n_cells * C7_NSTRIP;
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv7_err_kernel, dim3(grid), dim3(256), C7_LDS + 32, stream, a6, x, weff_dev, b7_dev, errpart,
-                       recon, (long)n_cells);
+    hipLaunchKernelGGL(conv7_err_kernel<TRAIN>, dim3(grid), dim3(256), LDS, stream, a6, x, weff_dev, b7_dev, errpart, recon,
+                       (long)n_cells, dz, dzsum_part);
     return hipGetLastError();
+}
+
+hipError_t launch_conv7_err(const float* a6, const float* x, const float* weff_dev, const float* b7_dev,
+                            float* errpart, float* recon, int64_t n_cells, hipStream_t stream)
+{
+    return launch_conv7_err_t<false>(a6, x, weff_dev, b7_dev, errpart, recon, nullptr, nullptr, n_cells, stream);
+}
+
+hipError_t launch_conv7_err_train(const float* a6, const float* x, const float* weff_dev, const float* b7_dev, float* errpart,
+                                  float* recon, float* dz, float* dzsum_part, int64_t n_cells, hipStream_t stream)
+{
+    return launch_conv7_err_t<true>(a6, x, weff_dev, b7_dev, errpart, recon, dz, dzsum_part, n_cells, stream);
 }
 
 }  // namespace cs

@@ -578,9 +578,17 @@ __global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict
 }
 
 // ============================================================== reduce / Adam / packing
-__global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad)
+// errpart != NULL: thread 0 also leaves the batch's {loss, mae} in out2 (the order of loss_scalar_kernel).
+__global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad,
+                                  const float* __restrict__ errpart, long nparts, long nelem, float* __restrict__ out2)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && errpart) {
+        double s2 = 0.0, s1 = 0.0;
+        for (long q = 0; q < nparts; ++q) { s2 += errpart[2 * q]; s1 += errpart[2 * q + 1]; }
+        out2[0] = (float)(s2 / (double)nelem);
+        out2[1] = (float)(s1 / (double)nelem);
+    }
     long base = 0;
     for (int d = 0; d < ndesc; ++d) {
         const ReduceDesc& D = descs[d];
@@ -806,9 +814,10 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
     }
 }
 
-hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s)
+hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s,
+                             const float* errpart, long nparts, long nelem, float* out2)
 {
-    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((total_len + 255) / 256)), dim3(256), 0, s, descs_dev, ndesc, flat_grad);
+    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((total_len + 255) / 256)), dim3(256), 0, s, descs_dev, ndesc, flat_grad, errpart, nparts, nelem, out2);
     return hipGetLastError();
 }
 

@@ -317,8 +317,10 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
         LCHK(launch_bn_apply(t->r[l].as<float>(), C, P + t->off_g[l], P + t->off_be[l], t->stats[l].as<float>(),
                              t->a[l].as<float>(), B, Hc, Hc, pool, s));
     }
-    LCHK(launch_conv7_err(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6],
-                          t->errpart.as<float>(), t->out.as<float>(), B, s));
+    // the output conv with the loss gradient in its epilogue: dz7 and its per-(cell, strip) sums (the bias gradient's partials)
+    LCHK(launch_conv7_err_train(t->a[5].as<float>(), t->y.as<float>(), t->w7eff.as<float>(), P + t->off_b[6], t->errpart.as<float>(),
+                                t->out.as<float>(), t->dz[6].as<float>(), t->dzsum_part[6].as<float>(), B, s));
+    t->np_b[6] = (int)(B * 4);
 
     // ---- backward -------------------------------------------------------------------------
     // The weight gradient of a layer needs only that layer's dz and input; it runs on a second stream beside the
@@ -330,8 +332,6 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
         HIPCHK(hipEventCreateWithFlags(&t->ev_wg, hipEventDisableTiming));
     }
     hipStream_t s2 = t->stream2;
-    LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * kH * kW, t->dz[6].as<float>(),
-                        t->dzsum_part[6].as<float>(), &t->np_b[6], s, t->errpart.as<float>(), B * 4, t->scal.as<float>()));
     HIPCHK(hipEventRecord(t->ev_dz[6], s));
     HIPCHK(hipStreamWaitEvent(s2, t->ev_dz[6], 0));
     LCHK(launch_wgrad(6, t->a[5].as<float>(), t->dz[6].as<float>(), t->wpart[6].as<float>(), B, &t->np_w[6], s2));
@@ -377,7 +377,8 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
         HIPCHK(hipStreamSynchronize(s));
         t->descs_batch = B;
     }
-    LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 14, total, G, s));
+    // ... and the batch's {loss, mae} from the forward pass's error partial sums (thread 0 of the same launch)
+    LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 14, total, G, s, t->errpart.as<float>(), B * 4, B * (long)kH * kW, t->scal.as<float>()));
     return CS_OK;
 }
 
