@@ -86,6 +86,7 @@ struct cs_model {
     bool x3conv3 = getenv("CS_NO_BF16X3_CONV3") == nullptr; // A/B knob: conv3's Winograd contraction on the fp32 matrix instructions
     bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
     bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
+    bool small_split = getenv("CS_NO_SMALL_SPLIT") == nullptr; // A/B knob: small calls (<= DET_SPLIT_MAX_CELLS) run the detector tail's ranges side by side
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
     bool h2conv6 = getenv("CS_NO_FP16X2_CONV6") == nullptr; // A/B knob: conv6 (in the fused conv6 + conv7 kernel) alone
@@ -106,6 +107,7 @@ struct cs_model {
     int64_t chunk = 0;     // cells per internal pass; 0 = automatic (eff_chunk), otherwise what cs_model_set_chunk asked for
     int64_t ws_cells = 0;
     DevBuf xin, xin2, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
+    DevBuf det_ws;      // range sums of the detector tail's split form (small calls)
     // profiling
     bool prof = false;
     std::vector<ProfEvent> pending;
@@ -446,6 +448,7 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
             if ((rc = m->act[l].ensure((size_t)cells * m->arch.floats[l] * sizeof(float)))) return rc;
         if ((rc = m->featE.ensure((size_t)cells * m->arch.feat() * sizeof(float)))) return rc;
         if ((rc = m->pca.ensure((size_t)cells * 256 * sizeof(float)))) return rc;
+        if (m->small_split && (rc = m->det_ws.ensure(det_split_ws_bytes(m->C)))) return rc;
         if ((rc = m->errpart.ensure((size_t)cells * 16 * sizeof(float)))) return rc;      // up to 8 partial (sq, abs) pairs per cell
         for (int d = 0; d < 2; ++d) {
             if ((rc = m->dec[d].ensure((size_t)cells * sizeof(double)))) return rc;
@@ -936,7 +939,7 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
     if (m->bf16x3 && m->x3pca)
         LAUNCH(K_SCALER_PCA, nc,
                launch_scaler_pca_x3(feat, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
-                                    m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+                                    m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream, m->det_ws.p));
     else
         LAUNCH(K_SCALER_PCA, nc,
                launch_scaler_pca(feat, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
@@ -944,7 +947,7 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
     for (int d = 0; d < 2; ++d)
         LAUNCH(K_SVM, nc,
                launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
-                            m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
+                            m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream, m->det_ws.p));
     LAUNCH(K_FINALIZE, nc,
            launch_finalize(with_err ? m->errpart.as<float>() : nullptr, m->errparts, (int)m->arch.npix, m->dec[0].as<double>(),
                            m->dec[1].as<double>(), mse, mae, sc, sm, pc, pm, nc, m->stream));
@@ -1146,7 +1149,7 @@ int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, fl
         if (m->bf16x3 && m->x3pca)
             LAUNCH(K_SCALER_PCA, nc,
                    launch_scaler_pca_x3(f, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
-                                        m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+                                        m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream, m->det_ws.p));
         else
             LAUNCH(K_SCALER_PCA, nc,
                    launch_scaler_pca(f, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
@@ -1180,7 +1183,7 @@ int cs_svm_decision(cs_model* m, const float* pca, int64_t n, int in_kind, doubl
             if (!outs[d]) continue;
             LAUNCH(K_SVM, nc,
                    launch_ocsvm(p, m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
-                                m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream));
+                                m->svm[d].nsv_pad, m->svm[d].gamma, m->svm[d].rho, m->dec[d].as<double>(), nc, m->stream, m->det_ws.p));
             HIPCHK(hipMemcpyAsync(outs[d] + off, m->dec[d].p, (size_t)nc * sizeof(double),
                                   out_kind == CS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->stream));
         }

@@ -251,13 +251,19 @@ hipError_t launch_scaler_pca(const float* feat, const float* center, const doubl
 // the same on the bf16 matrix pipe (six split products per multiply): comps_planes = pack_pca_bf16x3(comps_pad, cpad, fpad, .)
 hipError_t launch_scaler_pca_x3(const float* feat, const float* center, const double* scale, const uint16_t* comps_planes,
                                 const float* mean_proj, int F, int fpad, int C, int cpad, float* pca_out, int64_t n_cells,
-                                hipStream_t stream);
+                                hipStream_t stream, void* split_ws = nullptr);
+// Small calls (n <= DET_SPLIT_MAX_CELLS, split_ws != NULL: det_split_ws_bytes(C) bytes of device memory): the PCA GEMM's feature
+// ranges / the SVM's support-vector ranges run side by side in separate workgroups and are added in the order the one-workgroup
+// form adds them -- bit-identical results, a 128-cell call 0.65 -> 0.3 ms (the reference screens one sample per call).
+constexpr int64_t DET_SPLIT_MAX_CELLS = 16384;
+size_t det_split_ws_bytes(int C);
 size_t pack_pca_bf16x3(const float* comps_pad, int cpad, int fpad, uint16_t* dst);     // returns the number of bf16 values
 
 // One-class SVM decision for one detector.  sv: [nsv_pad][D] row-major, svT: [D][nsv_pad]
 // (transposed), coef: [nsv_pad]; all zero padded.  dec[n] = sum - rho.
 hipError_t launch_ocsvm(const float* pca, int D, const double* svT /* [D][nsv_pad] */, const double* svn /* ||sv||^2 */,
-                        const double* coef, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells, hipStream_t stream);
+                        const double* coef, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells, hipStream_t stream,
+                        void* split_ws = nullptr);
 
 // errpart -> mse/mae ; dec -> score (= -dec) and pred.
 hipError_t launch_finalize(const float* errpart, int nparts, int npix, const double* dec_c,

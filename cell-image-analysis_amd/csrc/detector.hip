@@ -138,10 +138,19 @@ constexpr int PX_ROW = PX_KC * 2 + 32;            // bytes per cell row of a pla
 constexpr int PX_PLANE = PCA_CELLS * PX_ROW;      // 18,432 B
 constexpr int PX_LDS = 3 * PX_PLANE;              // 55,296 B
 
+// The K = fpad features are summed in DET_RANGES fixed ranges of whole chunks: a range's products accumulate from zero in the
+// MFMA accumulators, the range sums are then added in ascending order (fp32).  SPLIT = false: one workgroup walks all ranges of
+// its 64 cells.  SPLIT = true: workgroup (x, j) computes range j alone and leaves its sum in part[j][cell][C]; pca_split_sum_kernel
+// adds the ranges in the same order -- the SAME arithmetic, so a cell's components do not depend on how many cells it is screened
+// with.  The split form is for small calls (the reference screens one sample of 1e2 .. 1e4 cells per call, improved_detection.py:199):
+// at 128 cells the unsplit kernel is two workgroups walking 2,048 features one chunk after the other (94 us).
+constexpr int DET_RANGES = 8;
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
     const float* __restrict__ feat, const float* __restrict__ center, const double* __restrict__ scale,
     const bf16x8* __restrict__ comps /* pack_pca_bf16x3 */, const float* __restrict__ mean_proj, int F, int fpad, int C,
-    int cpad, float* __restrict__ out, long n)
+    int cpad, float* __restrict__ out /* SPLIT: part [DET_RANGES][n][C] */, long n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,11 +160,15 @@ __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
     const int ntiles = cpad / 16;   // <= 8: wave w owns component tiles w and w + 4
     const int nkb = fpad / 32;
 
-    f32x4 acc[2][PCA_MT];
+    f32x4 acc[2][PCA_MT], tot[2][PCA_MT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int m = 0; m < PCA_MT; ++m) acc[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int m = 0; m < PCA_MT; ++m) acc[t][m] = tot[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nch = fpad / PX_KC;                // chunks; range j = chunks [nch j / R, nch (j + 1) / R)
+    int rj = SPLIT ? (int)blockIdx.y : 0;
+    const int kbeg = SPLIT ? (nch * rj / DET_RANGES) * PX_KC : 0;
+    const int kend = SPLIT ? (nch * (rj + 1) / DET_RANGES) * PX_KC : fpad;
 
     const int fp = tid & 63, cg = tid >> 6;      // feature pair of the chunk, 16-cell group
     float raw[16][2];
@@ -207,13 +220,15 @@ __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
 #pragma unroll
             for (int p = 0; p < 3; ++p) b[t][p] = bp[t][((size_t)kb * 3 + p) * 64];
     };
-    issue(0);
     bf16x8 bn[2][3];
-    load_b(0, bn);
-    for (int k0 = 0; k0 < fpad; k0 += PX_KC) {
+    if (kbeg < kend) {
+        issue(kbeg);
+        load_b(kbeg / 32, bn);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += PX_KC) {
         stash(k0);
         __syncthreads();
-        if (k0 + PX_KC < fpad) issue(k0 + PX_KC);
+        if (k0 + PX_KC < kend) issue(k0 + PX_KC);
 #pragma unroll
         for (int ks = 0; ks < PX_KC / 32; ++ks) {
             bf16x8 b[2][3];
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[t][p] = bn[t][p];
             const int kb = k0 / 32 + ks;
-            if (kb + 1 < nkb) load_b(kb + 1, bn);
+            if (kb + 1 < kend / 32) load_b(kb + 1, bn);
 #pragma unroll
             for (int m = 0; m < PCA_MT; ++m) {
                 const char* ap = smem + (m * 16 + li) * PX_ROW + ks * 64 + kq * 16;
@@ -243,22 +258,47 @@ __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
             }
         }
         __syncthreads();
+        // the end of a range (every empty range in between adds an exact zero): its sum joins the total
+        while (rj < DET_RANGES && (nch * (rj + 1) / DET_RANGES) * PX_KC <= k0 + PX_KC) {
+            if ((nch * (rj + 1) / DET_RANGES) * PX_KC == k0 + PX_KC) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int m = 0; m < PCA_MT; ++m) { tot[t][m] += acc[t][m]; acc[t][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+            }
+            ++rj;
+            if (SPLIT) break;
+        }
     }
     // D[row = 4 kq + r (cell)][col = li (component)]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int comp = (wave + 4 * t) * 16 + li;
         if (wave + 4 * t < ntiles && comp < C) {
-            const float mp = mean_proj[comp];
+            const float mp = SPLIT ? 0.0f : mean_proj[comp];
 #pragma unroll
             for (int m = 0; m < PCA_MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long cell = cell0 + m * 16 + 4 * kq + r;
-                    if (cell < n) out[cell * C + comp] = acc[t][m][r] - mp;
+                    if (cell < n) {
+                        if constexpr (SPLIT) out[((size_t)blockIdx.y * n + cell) * C + comp] = tot[t][m][r];
+                        else out[cell * C + comp] = tot[t][m][r] - mp;
+                    }
                 }
         }
     }
+}
+
+// out[cell][c] = ((P_0 + P_1) + ... + P_7) - mean_proj[c]: the order scaler_pca_x3_kernel<false> adds its ranges in
+__global__ void pca_split_sum_kernel(const float* __restrict__ part, const float* __restrict__ mean_proj, int C, float* __restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DET_RANGES; ++j) v += part[(size_t)j * n * C + i];
+    out[i] = v - mean_proj[i % C];
 }
 
 // ---------------------------------------------------------------- one-class SVM decision (fp64 MFMA)
@@ -274,11 +314,16 @@ __global__ __launch_bounds__(256) void scaler_pca_x3_kernel(
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SVMM_WAVES = 8, SVMM_TILES = 2, SVMM_CELLS = SVMM_WAVES * SVMM_TILES * 16;
 
-template <int KS>   // K steps of 4 components: D <= 4 KS
+// The support-vector blocks are summed in DET_RANGES fixed ranges: per lane over the blocks of a range, over the 16 lanes of a row
+// in a fixed tree, and the range sums in ascending order.  SPLIT = false: one workgroup walks all ranges of its 256 cells.  SPLIT =
+// true: workgroup (x, j) evaluates range j alone and leaves its sum in part[j][cell]; svm_split_sum_kernel adds the ranges in the
+// same order and subtracts rho -- the same arithmetic (see scaler_pca_x3_kernel).  For small calls: at 128 cells the unsplit
+// kernel is ONE workgroup walking ~27 blocks of double-precision exp() one after the other (167 us per detector).
+template <int KS, bool SPLIT>   // K steps of 4 components: D <= 4 KS
 __global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
     const float* __restrict__ pca, int D, const double* __restrict__ svT /* [D][nsv_pad] */,
     const double* __restrict__ svn /* [nsv_pad] ||s||^2 */, const double* __restrict__ coef /* [nsv_pad] */, int nsv_pad,
-    double gamma, double rho, double* __restrict__ dec, long n)
+    double gamma, double rho, double* __restrict__ dec /* SPLIT: part [DET_RANGES][n] */, long n)
 {
     constexpr int ROWS = 4 * KS + 2;                     // components (zero padded) + ||s||^2 row + coef row
     __shared__ double sb[2][ROWS][16];
@@ -328,22 +373,24 @@ __global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
         }
     };
     const int nblk = nsv_pad / 16;
-    {
+    int rj = SPLIT ? (int)blockIdx.y : 0;
+    const int bbeg = SPLIT ? nblk * rj / DET_RANGES : 0, bend = SPLIT ? nblk * (rj + 1) / DET_RANGES : nblk;
+    if (bbeg < bend) {
         double v[NST];
-        fetch(0, v);
-        stash(0, v);
+        fetch(bbeg, v);
+        stash(bbeg & 1, v);
     }
     __syncthreads();
 
-    double sum[SVMM_TILES][4];
+    double sum[SVMM_TILES][4], tot[SVMM_TILES][4];
 #pragma unroll
     for (int t = 0; t < SVMM_TILES; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sum[t][r] = 0.0;
-    for (int blk = 0; blk < nblk; ++blk) {
+        for (int r = 0; r < 4; ++r) sum[t][r] = tot[t][r] = 0.0;
+    for (int blk = bbeg; blk < bend; ++blk) {
         const int cur = blk & 1;
         double nv[NST];
-        if (blk + 1 < nblk) fetch(blk + 1, nv);
+        if (blk + 1 < bend) fetch(blk + 1, nv);
         f64x4 acc[SVMM_TILES];
 #pragma unroll
         for (int t = 0; t < SVMM_TILES; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -361,21 +408,49 @@ __global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
                 const double d2 = fma(-2.0, acc[t][r], rown[t][r] + sn);
                 sum[t][r] = fma(cf, exp(-gamma * d2), sum[t][r]);
             }
-        if (blk + 1 < nblk) stash(cur ^ 1, nv);
+        if (blk + 1 < bend) stash(cur ^ 1, nv);
         __syncthreads();
+        // the end of a range: its 16 lane sums in a fixed tree, the result added to the total (an empty range adds an exact zero)
+        while (rj < DET_RANGES && nblk * (rj + 1) / DET_RANGES <= blk + 1) {
+            if (nblk * (rj + 1) / DET_RANGES == blk + 1) {
+#pragma unroll
+                for (int t = 0; t < SVMM_TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double v = sum[t][r];
+                        v += __shfl_xor(v, 1);
+                        v += __shfl_xor(v, 2);
+                        v += __shfl_xor(v, 4);
+                        v += __shfl_xor(v, 8);
+                        tot[t][r] += v;
+                        sum[t][r] = 0.0;
+                    }
+            }
+            ++rj;
+            if (SPLIT) break;
+        }
     }
 #pragma unroll
     for (int t = 0; t < SVMM_TILES; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double v = sum[t][r];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
             const long cell = cell0 + t * 16 + kq + 4 * r;
-            if (li == 0 && cell < n) dec[cell] = v - rho;
+            if (li == 0 && cell < n) {
+                if constexpr (SPLIT) dec[(size_t)blockIdx.y * n + cell] = tot[t][r];
+                else dec[cell] = tot[t][r] - rho;
+            }
         }
+}
+
+// dec[cell] = ((P_0 + P_1) + ... + P_7) - rho: the order ocsvm_mfma_kernel<KS, false> adds its ranges in
+__global__ void svm_split_sum_kernel(const double* __restrict__ part, double rho, double* __restrict__ dec, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < DET_RANGES; ++j) v += part[(size_t)j * n + i];
+    dec[i] = v - rho;
 }
 
 
@@ -484,35 +559,64 @@ size_t pack_pca_bf16x3(const float* comps_pad, int cpad, int fpad, uint16_t* dst
     return n;
 }
 
+size_t det_split_ws_bytes(int C)
+{
+    const size_t pca = (size_t)DET_RANGES * DET_SPLIT_MAX_CELLS * (size_t)C * sizeof(float);
+    const size_t svm = (size_t)DET_RANGES * DET_SPLIT_MAX_CELLS * sizeof(double);
+    return pca > svm ? pca : svm;
+}
+
 hipError_t launch_scaler_pca_x3(const float* feat, const float* center, const double* scale, const uint16_t* comps_planes,
                                 const float* mean_proj, int F, int fpad, int C, int cpad, float* pca_out, int64_t n_cells,
-                                hipStream_t stream)
+                                hipStream_t stream, void* split_ws)
 {
     if (n_cells <= 0) return hipSuccess;
     if (cpad % 16 || cpad > 128 || fpad % PX_KC) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_cells + PCA_CELLS - 1) / PCA_CELLS);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)scaler_pca_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)scaler_pca_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)scaler_pca_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(scaler_pca_x3_kernel, dim3(grid), dim3(256), PX_LDS, stream, feat, center, scale, (const bf16x8*)comps_planes,
+    if (split_ws && n_cells <= DET_SPLIT_MAX_CELLS) {       // a small call: the ranges side by side, then their sum in the same order
+        hipLaunchKernelGGL(scaler_pca_x3_kernel<true>, dim3(grid, DET_RANGES), dim3(256), PX_LDS, stream, feat, center, scale,
+                           (const bf16x8*)comps_planes, mean_proj, F, fpad, C, cpad, (float*)split_ws, (long)n_cells);
+        const long tot = (long)n_cells * C;
+        hipLaunchKernelGGL(pca_split_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (const float*)split_ws, mean_proj,
+                           C, pca_out, (long)n_cells);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(scaler_pca_x3_kernel<false>, dim3(grid), dim3(256), PX_LDS, stream, feat, center, scale, (const bf16x8*)comps_planes,
                        mean_proj, F, fpad, C, cpad, pca_out, (long)n_cells);
     return hipGetLastError();
 }
 
 hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* svn, const double* coef, int nsv_pad, double gamma,
-                        double rho, double* dec, int64_t n_cells, hipStream_t stream)
+                        double rho, double* dec, int64_t n_cells, hipStream_t stream, void* split_ws)
 {
     if (n_cells <= 0) return hipSuccess;
     if (!svT || !svn || !coef || D < 1 || D > 128 || nsv_pad % 16) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_cells + SVMM_CELLS - 1) / SVMM_CELLS);
+    if (split_ws && n_cells <= DET_SPLIT_MAX_CELLS) {
+        double* part = (double*)split_ws;
+        if (D <= 100)
+            hipLaunchKernelGGL((ocsvm_mfma_kernel<25, true>), dim3(grid, DET_RANGES), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef,
+                               nsv_pad, gamma, rho, part, (long)n_cells);
+        else
+            hipLaunchKernelGGL((ocsvm_mfma_kernel<32, true>), dim3(grid, DET_RANGES), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef,
+                               nsv_pad, gamma, rho, part, (long)n_cells);
+        hipLaunchKernelGGL(svm_split_sum_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, (const double*)part, rho, dec,
+                           (long)n_cells);
+        return hipGetLastError();
+    }
     if (D <= 100)   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
-        hipLaunchKernelGGL(ocsvm_mfma_kernel<25>, dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
+        hipLaunchKernelGGL((ocsvm_mfma_kernel<25, false>), dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
                            rho, dec, (long)n_cells);
     else
-        hipLaunchKernelGGL(ocsvm_mfma_kernel<32>, dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
+        hipLaunchKernelGGL((ocsvm_mfma_kernel<32, false>), dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
                            rho, dec, (long)n_cells);
     return hipGetLastError();
 }

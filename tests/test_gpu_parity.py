@@ -148,6 +148,37 @@ def test_fp16_split_results_do_not_depend_on_the_batch(weights, det):
         e.close()
 
 
+def test_small_calls_run_the_detector_tail_split_with_identical_results(weights, det, monkeypatch):
+    """A call of at most 16,384 cells runs the PCA GEMM's feature ranges and the SVMs' support-vector ranges side by side in separate
+    workgroups (a 128-cell call is otherwise two workgroups / one workgroup walking everything in sequence) and adds the range sums in
+    the order the one-workgroup kernels add them: every output is bit-identical to the same cells screened inside a large call, and to
+    the one-workgroup form forced by CS_NO_SMALL_SPLIT=1."""
+    n_big = 16384 + 700
+    x = oracle.synth_crops(23, 0, n_big)
+    e = Engine.from_weights(weights, None, det)
+    try:
+        whole = e.screen(x)                                  # above the limit: the one-workgroup kernels
+        f = e.encode(x[:300])
+        pca_small = e.scaler_pca(f)                          # 300 cells: split
+        pca_big = e.scaler_pca(e.encode(x))[:300]            # the same cells inside 17,084: not split
+        assert np.array_equal(pca_small, pca_big)
+        for idx in (slice(0, 1), slice(0, 300), slice(300, 1337), slice(0, 16384)):
+            part = e.screen(x[idx])
+            for k in whole:
+                assert np.array_equal(part[k], whole[k][idx]), (k, idx)
+    finally:
+        e.close()
+    monkeypatch.setenv("CS_NO_SMALL_SPLIT", "1")
+    e1 = Engine.from_weights(weights, None, det)
+    monkeypatch.delenv("CS_NO_SMALL_SPLIT")
+    try:
+        one = e1.screen(x[:300])
+        for k in whole:
+            assert np.array_equal(one[k], whole[k][:300]), k
+    finally:
+        e1.close()
+
+
 def test_conv3_winograd_on_the_16_bit_pipe_is_in_the_fp32_error_class(weights, crops, monkeypatch):
     """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs as a two-term fp16 split by default
     (conv3_wino_h2_kernel, 768 MFMAs per cell), as the three-term bf16 split behind CS_NO_FP16X2 (conv3_wino_x3_kernel, 1,536) and on
