@@ -68,6 +68,8 @@ struct Arch {
 
 struct ProfEvent { int kid; hipEvent_t a, b; int64_t cells; };
 
+constexpr int64_t kPackedResultCells = 65536;   // cs_screen: host results of calls up to this size come back in one copy
+
 struct cs_model {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -108,6 +110,9 @@ struct cs_model {
     int64_t ws_cells = 0;
     DevBuf xin, xin2, act[CS_MAX_CONV], featE, pca, errpart, dec[2], o_mse, o_mae, o_sc[2], o_pr[2], recon;
     DevBuf det_ws;      // range sums of the detector tail's split form (small calls)
+    DevBuf o_pack;      // cs_screen's host results, collected on the device: six arrays back to back
+    void* h_pack = nullptr;             // pinned landing buffer of a small call's results
+    size_t h_pack_bytes = 0;
     // profiling
     bool prof = false;
     std::vector<ProfEvent> pending;
@@ -116,6 +121,7 @@ struct cs_model {
     int64_t prof_cells[K_COUNT] = {0};
     ~cs_model()
     {
+        if (h_pack) (void)hipHostFree(h_pack);
         for (auto& e : pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int i = 0; i < 2; ++i) {
             if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
@@ -944,6 +950,16 @@ static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, floa
         LAUNCH(K_SCALER_PCA, nc,
                launch_scaler_pca(feat, m->center.as<float>(), m->scale.as<double>(), m->comps.as<float>(),
                                  m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream));
+    if (m->det_ws.p && nc <= DET_SPLIT_MAX_CELLS) {       // a small call: both detectors' ranges in one launch
+        const double* svT[2] = {m->svm[0].svT.as<double>(), m->svm[1].svT.as<double>()};
+        const double* svn[2] = {m->svm[0].svn.as<double>(), m->svm[1].svn.as<double>()};
+        const double* coef[2] = {m->svm[0].coef.as<double>(), m->svm[1].coef.as<double>()};
+        const int nsv[2] = {m->svm[0].nsv_pad, m->svm[1].nsv_pad};
+        const double gam[2] = {m->svm[0].gamma, m->svm[1].gamma}, rho[2] = {m->svm[0].rho, m->svm[1].rho};
+        LAUNCH(K_SVM, nc,
+               launch_ocsvm_pair_split(m->pca.as<float>(), m->C, svT, svn, coef, nsv, gam, rho, m->dec[0].as<double>(), m->dec[1].as<double>(), nc,
+                                       m->stream, m->det_ws.p));
+    } else
     for (int d = 0; d < 2; ++d)
         LAUNCH(K_SVM, nc,
                launch_ocsvm(m->pca.as<float>(), m->C, m->svm[d].svT.as<double>(), m->svm[d].svn.as<double>(), m->svm[d].coef.as<double>(),
@@ -974,20 +990,32 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
     const bool host_in = crops_kind == CS_MEM_HOST, host_out = out_kind == CS_MEM_HOST;
     const size_t in_bytes = m->arch.npix * sizeof(float);
     DevBuf* stage[2] = {&m->xin, &m->xin2};
+    const bool single = n <= ch;
     if (host_in) {
         if ((rc = m->xin.ensure((size_t)ch * in_bytes)) || (n > ch && (rc = m->xin2.ensure((size_t)ch * in_bytes)))) return rc;
-        HIPCHK(hipMemcpyAsync(m->xin.p, crops, (size_t)ch * in_bytes, hipMemcpyHostToDevice, m->copy_stream));
-        HIPCHK(hipEventRecord(m->ev_in[0], m->copy_stream));
+        // a call of one chunk has nothing to overlap: its crops go up on the compute stream itself (no second stream, no event)
+        HIPCHK(hipMemcpyAsync(m->xin.p, crops, (size_t)ch * in_bytes, hipMemcpyHostToDevice, single ? m->stream : m->copy_stream));
+        if (!single) HIPCHK(hipEventRecord(m->ev_in[0], m->copy_stream));
     }
+    // host results: the six arrays back to back in ONE device buffer ([n] double x 2, [n] float x 2, [n] int8 x 2).  A small call
+    // (the reference screens one sample of 1e2 .. 1e4 cells per call) fetches them with one copy into pinned memory and hands them
+    // out with memcpy -- six copies into pageable memory cost 6 x ~10 us of a 0.3 ms call; a large call copies each array directly.
+    const size_t o_off[6] = {0, (size_t)n * 8, (size_t)n * 16, (size_t)n * 20, (size_t)n * 24, (size_t)n * 25};   // sc0 sc1 mse mae pr0 pr1
+    const size_t o_total = (size_t)n * 26;
+    const bool pack_out = host_out && n <= kPackedResultCells;
     if (host_out) {
-        if ((mse && (rc = m->o_mse.ensure((size_t)n * sizeof(float)))) || (mae && (rc = m->o_mae.ensure((size_t)n * sizeof(float)))) ||
-            (cons_score && (rc = m->o_sc[0].ensure((size_t)n * sizeof(double)))) || (mod_score && (rc = m->o_sc[1].ensure((size_t)n * sizeof(double)))) ||
-            (cons_pred && (rc = m->o_pr[0].ensure((size_t)n))) || (mod_pred && (rc = m->o_pr[1].ensure((size_t)n))))
-            return rc;
+        if ((rc = m->o_pack.ensure(o_total))) return rc;
+        if (pack_out && m->h_pack_bytes < o_total) {
+            if (m->h_pack) { (void)hipHostFree(m->h_pack); m->h_pack = nullptr; m->h_pack_bytes = 0; }
+            const size_t cap = (size_t)kPackedResultCells * 26;
+            HIPCHK(hipHostMalloc(&m->h_pack, cap, hipHostMallocDefault));
+            m->h_pack_bytes = cap;
+        }
     }
-    auto dst = [&](auto* user, DevBuf& tmp, int64_t off) -> decltype(user) {
+    char* const o_base = (char*)m->o_pack.p;
+    auto dst = [&](auto* user, int which, int64_t off) -> decltype(user) {
         if (!user) return nullptr;
-        return host_out ? (decltype(user))tmp.p + off : user + off;
+        return host_out ? (decltype(user))(o_base + o_off[which]) + off : user + off;
     };
     // an error inside the pipeline must not return while a copy from the caller's host buffer is still in flight
     auto drain = [&](int code) {
@@ -1001,7 +1029,7 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
         const int b = (int)(i & 1);
         const float* x = crops + (size_t)off * m->arch.npix;
         if (host_in) {
-            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_in[b], 0));
+            if (!single) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_in[b], 0));
             x = stage[b]->as<float>();
         }
         if ((rc = run_convs(m, m->ae, x, nc, 0, m->arch.n_conv - 1, nullptr))) return drain(rc);
@@ -1012,10 +1040,10 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
             if ((rc = run_convs(m, m->enc, x, nc, 0, m->arch.n_enc - 1, nullptr))) return drain(rc);
             feat = m->act[m->arch.n_enc - 1].as<float>();
         }
-        if ((rc = run_tail(m, feat, nc, dst(mse, m->o_mse, off), dst(mae, m->o_mae, off), dst(cons_score, m->o_sc[0], off),
-                           dst(mod_score, m->o_sc[1], off), dst(cons_pred, m->o_pr[0], off), dst(mod_pred, m->o_pr[1], off), true)))
+        if ((rc = run_tail(m, feat, nc, dst(mse, 2, off), dst(mae, 3, off), dst(cons_score, 0, off),
+                           dst(mod_score, 1, off), dst(cons_pred, 4, off), dst(mod_pred, 5, off), true)))
             return drain(rc);
-        if (host_in) {
+        if (host_in && !single) {
             HIPCHK(hipEventRecord(m->ev_used[b], m->stream));
             const int64_t noff = off + ch;
             if (noff < n) {   // next chunk into the other buffer, once the chunk before this one has released it
@@ -1027,13 +1055,27 @@ int cs_screen(cs_model* m, const float* crops, int64_t n, int crops_kind, float*
             }
         }
     }
+    if (pack_out) {
+        HIPCHK(hipMemcpyAsync(m->h_pack, o_base, o_total, hipMemcpyDeviceToHost, m->stream));
+        if (host_in) HIPCHK(hipStreamSynchronize(m->copy_stream));
+        const int erc = end_call(m);                     // synchronises the handle's stream: the packed results are on the host
+        if (erc) return guard.done(erc);
+        const char* h = (const char*)m->h_pack;
+        if (cons_score) memcpy(cons_score, h + o_off[0], (size_t)n * 8);
+        if (mod_score) memcpy(mod_score, h + o_off[1], (size_t)n * 8);
+        if (mse) memcpy(mse, h + o_off[2], (size_t)n * 4);
+        if (mae) memcpy(mae, h + o_off[3], (size_t)n * 4);
+        if (cons_pred) memcpy(cons_pred, h + o_off[4], (size_t)n);
+        if (mod_pred) memcpy(mod_pred, h + o_off[5], (size_t)n);
+        return guard.done(CS_OK);
+    }
     if (host_out) {
-        if (mse) HIPCHK(hipMemcpyAsync(mse, m->o_mse.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-        if (mae) HIPCHK(hipMemcpyAsync(mae, m->o_mae.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-        if (cons_score) HIPCHK(hipMemcpyAsync(cons_score, m->o_sc[0].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-        if (mod_score) HIPCHK(hipMemcpyAsync(mod_score, m->o_sc[1].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
-        if (cons_pred) HIPCHK(hipMemcpyAsync(cons_pred, m->o_pr[0].p, (size_t)n, hipMemcpyDeviceToHost, m->stream));
-        if (mod_pred) HIPCHK(hipMemcpyAsync(mod_pred, m->o_pr[1].p, (size_t)n, hipMemcpyDeviceToHost, m->stream));
+        if (mse) HIPCHK(hipMemcpyAsync(mse, o_base + o_off[2], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (mae) HIPCHK(hipMemcpyAsync(mae, o_base + o_off[3], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (cons_score) HIPCHK(hipMemcpyAsync(cons_score, o_base + o_off[0], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        if (mod_score) HIPCHK(hipMemcpyAsync(mod_score, o_base + o_off[1], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        if (cons_pred) HIPCHK(hipMemcpyAsync(cons_pred, o_base + o_off[4], (size_t)n, hipMemcpyDeviceToHost, m->stream));
+        if (mod_pred) HIPCHK(hipMemcpyAsync(mod_pred, o_base + o_off[5], (size_t)n, hipMemcpyDeviceToHost, m->stream));
     }
     if (host_in) HIPCHK(hipStreamSynchronize(m->copy_stream));
     return guard.done(end_call(m));

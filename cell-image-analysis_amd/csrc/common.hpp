@@ -265,6 +265,10 @@ hipError_t launch_ocsvm(const float* pca, int D, const double* svT /* [D][nsv_pa
                         const double* coef, int nsv_pad, double gamma, double rho, double* dec, int64_t n_cells, hipStream_t stream,
                         void* split_ws = nullptr);
 
+hipError_t launch_ocsvm_pair_split(const float* pca, int D, const double* const svT[2], const double* const svn[2],
+                                   const double* const coef[2], const int nsv_pad[2], const double gamma[2], const double rho[2],
+                                   double* dec0, double* dec1, int64_t n_cells, hipStream_t stream, void* split_ws);
+
 // errpart -> mse/mae ; dec -> score (= -dec) and pred.
 hipError_t launch_finalize(const float* errpart, int nparts, int npix, const double* dec_c,
                            const double* dec_m, float* mse, float* mae, double* score_c,

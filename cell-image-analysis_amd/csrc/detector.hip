@@ -319,12 +319,25 @@ constexpr int SVMM_WAVES = 8, SVMM_TILES = 2, SVMM_CELLS = SVMM_WAVES * SVMM_TIL
 // true: workgroup (x, j) evaluates range j alone and leaves its sum in part[j][cell]; svm_split_sum_kernel adds the ranges in the
 // same order and subtracts rho -- the same arithmetic (see scaler_pca_x3_kernel).  For small calls: at 128 cells the unsplit
 // kernel is ONE workgroup walking ~27 blocks of double-precision exp() one after the other (167 us per detector).
+// one or two detectors per launch (blockIdx.z picks): the split form runs both side by side
+struct SvmArgs {
+    const double* svT[2];       // [D][nsv_pad]
+    const double* svn[2];       // [nsv_pad] ||s||^2
+    const double* coef[2];      // [nsv_pad]
+    int nsv_pad[2];
+    double gamma[2], rho[2];
+};
+
 template <int KS, bool SPLIT>   // K steps of 4 components: D <= 4 KS
 __global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
-    const float* __restrict__ pca, int D, const double* __restrict__ svT /* [D][nsv_pad] */,
-    const double* __restrict__ svn /* [nsv_pad] ||s||^2 */, const double* __restrict__ coef /* [nsv_pad] */, int nsv_pad,
-    double gamma, double rho, double* __restrict__ dec /* SPLIT: part [DET_RANGES][n] */, long n)
+    const float* __restrict__ pca, int D, SvmArgs sa, double* __restrict__ dec /* SPLIT: part [detector][DET_RANGES][n] */, long n)
 {
+    const int det = (int)blockIdx.z;
+    const double* __restrict__ svT = sa.svT[det];
+    const double* __restrict__ svn = sa.svn[det];
+    const double* __restrict__ coef = sa.coef[det];
+    const int nsv_pad = sa.nsv_pad[det];
+    const double gamma = sa.gamma[det], rho = sa.rho[det];
     constexpr int ROWS = 4 * KS + 2;                     // components (zero padded) + ||s||^2 row + coef row
     __shared__ double sb[2][ROWS][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,21 +449,24 @@ __global__ __launch_bounds__(64 * SVMM_WAVES, 1) void ocsvm_mfma_kernel(
         for (int r = 0; r < 4; ++r) {
             const long cell = cell0 + t * 16 + kq + 4 * r;
             if (li == 0 && cell < n) {
-                if constexpr (SPLIT) dec[(size_t)blockIdx.y * n + cell] = tot[t][r];
+                if constexpr (SPLIT) dec[((size_t)det * DET_RANGES + blockIdx.y) * n + cell] = tot[t][r];
                 else dec[cell] = tot[t][r] - rho;
             }
         }
 }
 
 // dec[cell] = ((P_0 + P_1) + ... + P_7) - rho: the order ocsvm_mfma_kernel<KS, false> adds its ranges in
-__global__ void svm_split_sum_kernel(const double* __restrict__ part, double rho, double* __restrict__ dec, long n)
+__global__ void svm_split_sum_kernel(const double* __restrict__ part, double rho0, double rho1, double* __restrict__ dec0,
+                                     double* __restrict__ dec1, long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int det = (int)blockIdx.y;
     if (i >= n) return;
     double v = 0.0;
 #pragma unroll
-    for (int j = 0; j < DET_RANGES; ++j) v += part[(size_t)j * n + i];
-    dec[i] = v - rho;
+    for (int j = 0; j < DET_RANGES; ++j) v += part[((size_t)det * DET_RANGES + j) * n + i];
+    if (det == 0) dec0[i] = v - rho0;
+    else dec1[i] = v - rho1;
 }
 
 
@@ -562,7 +578,7 @@ size_t pack_pca_bf16x3(const float* comps_pad, int cpad, int fpad, uint16_t* dst
 size_t det_split_ws_bytes(int C)
 {
     const size_t pca = (size_t)DET_RANGES * DET_SPLIT_MAX_CELLS * (size_t)C * sizeof(float);
-    const size_t svm = (size_t)DET_RANGES * DET_SPLIT_MAX_CELLS * sizeof(double);
+    const size_t svm = (size_t)2 * DET_RANGES * DET_SPLIT_MAX_CELLS * sizeof(double);
     return pca > svm ? pca : svm;
 }
 
@@ -594,30 +610,44 @@ hipError_t launch_scaler_pca_x3(const float* feat, const float* center, const do
     return hipGetLastError();
 }
 
+template <bool SPLIT>
+static void ocsvm_launch(const float* pca, int D, const SvmArgs& sa, double* out, int64_t n_cells, dim3 grid, hipStream_t stream)
+{
+    if (D <= 100)   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
+        hipLaunchKernelGGL((ocsvm_mfma_kernel<25, SPLIT>), grid, dim3(64 * SVMM_WAVES), 0, stream, pca, D, sa, out, (long)n_cells);
+    else
+        hipLaunchKernelGGL((ocsvm_mfma_kernel<32, SPLIT>), grid, dim3(64 * SVMM_WAVES), 0, stream, pca, D, sa, out, (long)n_cells);
+}
+
 hipError_t launch_ocsvm(const float* pca, int D, const double* svT, const double* svn, const double* coef, int nsv_pad, double gamma,
                         double rho, double* dec, int64_t n_cells, hipStream_t stream, void* split_ws)
 {
     if (n_cells <= 0) return hipSuccess;
     if (!svT || !svn || !coef || D < 1 || D > 128 || nsv_pad % 16) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n_cells + SVMM_CELLS - 1) / SVMM_CELLS);
+    SvmArgs sa{{svT, svT}, {svn, svn}, {coef, coef}, {nsv_pad, nsv_pad}, {gamma, gamma}, {rho, rho}};
     if (split_ws && n_cells <= DET_SPLIT_MAX_CELLS) {
-        double* part = (double*)split_ws;
-        if (D <= 100)
-            hipLaunchKernelGGL((ocsvm_mfma_kernel<25, true>), dim3(grid, DET_RANGES), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef,
-                               nsv_pad, gamma, rho, part, (long)n_cells);
-        else
-            hipLaunchKernelGGL((ocsvm_mfma_kernel<32, true>), dim3(grid, DET_RANGES), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef,
-                               nsv_pad, gamma, rho, part, (long)n_cells);
-        hipLaunchKernelGGL(svm_split_sum_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, (const double*)part, rho, dec,
-                           (long)n_cells);
+        ocsvm_launch<true>(pca, D, sa, (double*)split_ws, n_cells, dim3(grid, DET_RANGES, 1), stream);
+        hipLaunchKernelGGL(svm_split_sum_kernel, dim3((unsigned)((n_cells + 255) / 256), 1), dim3(256), 0, stream, (const double*)split_ws, rho, rho,
+                           dec, dec, (long)n_cells);
         return hipGetLastError();
     }
-    if (D <= 100)   // the reference's n_components (CAE_improved_modeltrain.py:412) whenever N_train > 100
-        hipLaunchKernelGGL((ocsvm_mfma_kernel<25, false>), dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
-                           rho, dec, (long)n_cells);
-    else
-        hipLaunchKernelGGL((ocsvm_mfma_kernel<32, false>), dim3(grid), dim3(64 * SVMM_WAVES), 0, stream, pca, D, svT, svn, coef, nsv_pad, gamma,
-                           rho, dec, (long)n_cells);
+    ocsvm_launch<false>(pca, D, sa, dec, n_cells, dim3(grid), stream);
+    return hipGetLastError();
+}
+
+// both detectors of a SMALL call in one launch (and one sum): n_cells <= DET_SPLIT_MAX_CELLS, split_ws = det_split_ws_bytes(C) bytes
+hipError_t launch_ocsvm_pair_split(const float* pca, int D, const double* const svT[2], const double* const svn[2],
+                                   const double* const coef[2], const int nsv_pad[2], const double gamma[2], const double rho[2],
+                                   double* dec0, double* dec1, int64_t n_cells, hipStream_t stream, void* split_ws)
+{
+    if (n_cells <= 0) return hipSuccess;
+    if (!split_ws || n_cells > DET_SPLIT_MAX_CELLS || D < 1 || D > 128 || nsv_pad[0] % 16 || nsv_pad[1] % 16) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_cells + SVMM_CELLS - 1) / SVMM_CELLS);
+    SvmArgs sa{{svT[0], svT[1]}, {svn[0], svn[1]}, {coef[0], coef[1]}, {nsv_pad[0], nsv_pad[1]}, {gamma[0], gamma[1]}, {rho[0], rho[1]}};
+    ocsvm_launch<true>(pca, D, sa, (double*)split_ws, n_cells, dim3(grid, DET_RANGES, 2), stream);
+    hipLaunchKernelGGL(svm_split_sum_kernel, dim3((unsigned)((n_cells + 255) / 256), 2), dim3(256), 0, stream, (const double*)split_ws, rho[0], rho[1],
+                       dec0, dec1, (long)n_cells);
     return hipGetLastError();
 }
 
