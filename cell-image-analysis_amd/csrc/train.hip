@@ -14,18 +14,22 @@ namespace {
 // r: [P][C] relu output (P = batch*H*W pixels).  Each workgroup reduces a contiguous pixel range
 // to {count, mean, M2} per channel (two passes over its range: exact local mean first), the
 // consumers merge the G partials with Chan's formula in double.
+// (a thread owns four adjacent channels of every L-th pixel of the range: 16-byte loads -- these kernels stream a tensor once
+// and are bound by the bytes they keep in flight, not by arithmetic)
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ r, long P, int C,
                                                                float* __restrict__ part /*[G][3][C]*/)
 {
-    __shared__ float red[256];
+    __shared__ float red[1024];
     __shared__ float meanc[256];
     const int tid = threadIdx.x;
-    const int c = tid % C, lane = tid / C, L = 256 / C;
+    const int C4 = C >> 2, c4 = tid % C4, lane = tid / C4, L = 256 / C4;
     const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
-    float s = 0.0f;
-#pragma unroll 8
-    for (long p = p0 + lane; p < p1; p += L) s += r[p * C + c];
-    red[tid] = s;
+    const f32x4* __restrict__ r4 = (const f32x4*)r;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (long p = p0 + lane; p < p1; p += L) s += r4[p * C4 + c4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[lane * C + 4 * c4 + j] = s[j];
     __syncthreads();
     if (tid < C) {
         float t = 0.0f;
@@ -33,12 +37,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         meanc[tid] = t / (float)(p1 - p0);
     }
     __syncthreads();
-    const float mu = meanc[c];
-    float m2 = 0.0f;
-#pragma unroll 8
-    for (long p = p0 + lane; p < p1; p += L) { const float d = r[p * C + c] - mu; m2 = fmaf(d, d, m2); }
+    const f32x4 mu = {meanc[4 * c4], meanc[4 * c4 + 1], meanc[4 * c4 + 2], meanc[4 * c4 + 3]};
+    f32x4 m2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (long p = p0 + lane; p < p1; p += L) { const f32x4 d = r4[p * C4 + c4] - mu; m2 += d * d; }
     __syncthreads();
-    red[tid] = m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[lane * C + 4 * c4 + j] = m2[j];
     __syncthreads();
     if (tid < C) {
         float t = 0.0f;
@@ -138,28 +143,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const float* __restrict__ r, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats /*[2][C]*/, float* __restrict__ a, long N, int H, int W, int pool)
 {
-    __shared__ float sm[256], si[256], sg[256], sb[256];
+    __shared__ float sg[256], sb[256];
     const int tid = threadIdx.x;
-    if (tid < C) { sm[tid] = stats[tid]; si[tid] = stats[C + tid]; sg[tid] = gamma[tid]; sb[tid] = beta[tid]; }
+    if (tid < C) {
+        const float g = gamma[tid] * stats[C + tid];
+        sg[tid] = g;                                  // y = r*g + b
+        sb[tid] = beta[tid] - stats[tid] * g;
+    }
     __syncthreads();
-    // H, W, C are powers of two and batch*H*W*C < 2^31: 32-bit shift/mask indexing (64-bit integer
-    // division costs far more than the arithmetic of these kernels)
-    const int lC = __ffs(C) - 1, lW = __ffs(W) - 1, lH = __ffs(H) - 1;
+    // H, W, C are powers of two and batch*H*W*C < 2^31: 32-bit shift/mask indexing; a thread owns four adjacent channels
+    const int C4 = C >> 2, lC4 = __ffs(C4) - 1, lW = __ffs(W) - 1, lH = __ffs(H) - 1;
     const int lWo = pool ? lW - 1 : lW, lHo = pool ? lH - 1 : lH;
-    const int total = (int)(N << (lHo + lWo + lC));
-#pragma unroll 4
-    for (int o = blockIdx.x * 256 + tid; o < total; o += gridDim.x * 256) {
-        const int c = o & (C - 1);
-        const int pix = o >> lC;
-        const float g = sg[c] * si[c], b = sb[c] - sm[c] * g;   // y = r*g + b
+    const int total4 = (int)(N << (lHo + lWo + lC4));
+    const f32x4* __restrict__ r4 = (const f32x4*)r;
+    f32x4* __restrict__ a4 = (f32x4*)a;
+#pragma unroll 2
+    for (int o = blockIdx.x * 256 + tid; o < total4; o += gridDim.x * 256) {
+        const int c4 = o & (C4 - 1);
+        const int pix = o >> lC4;
+        const f32x4 g = *(const f32x4*)&sg[4 * c4], b = *(const f32x4*)&sb[4 * c4];
+        auto bn = [&](const f32x4& v) { return f32x4{fmaf(v[0], g[0], b[0]), fmaf(v[1], g[1], b[1]), fmaf(v[2], g[2], b[2]), fmaf(v[3], g[3], b[3])}; };
         if (pool) {
             const int xo = pix & ((1 << lWo) - 1), yo = (pix >> lWo) & ((1 << lHo) - 1), n = pix >> (lWo + lHo);
-            const float* p = r + ((((size_t)n << lH) + 2 * yo) << lW) * C + (size_t)(2 * xo) * C + c;
-            const float y00 = fmaf(p[0], g, b), y01 = fmaf(p[C], g, b);
-            const float y10 = fmaf(p[(size_t)W * C], g, b), y11 = fmaf(p[(size_t)W * C + C], g, b);
-            a[o] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+            const f32x4* p = r4 + ((((size_t)n << lH) + 2 * yo) << lW) * C4 + (size_t)(2 * xo) * C4 + c4;
+            const f32x4 y00 = bn(p[0]), y01 = bn(p[C4]), y10 = bn(p[(size_t)W * C4]), y11 = bn(p[(size_t)W * C4 + C4]);
+            f32x4 m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(y00[j], y01[j]), fmaxf(y10[j], y11[j]));
+            a4[o] = m;
         } else {
-            a[o] = fmaf(r[o], g, b);
+            a4[o] = bn(r4[o]);
         }
     }
 }
@@ -208,25 +221,30 @@ __global__ void loss_scalar_kernel(const float* __restrict__ errpart, long npart
 // Gradient arriving at the BN output: `da` at pooled resolution for encoder layers (MaxPooling2D
 // routes it to the arg-max of each 2x2 window of y = BN(r), first maximum in (dy,dx) order),
 // at full resolution for decoder layers.
-struct Win { float dy[4]; float xh[4]; float r[4]; };
+// A thread owns four adjacent channels (16-byte loads) of every L-th (pooled) pixel of its workgroup's range.
+struct Win4 { f32x4 dy[4]; f32x4 xh[4]; f32x4 r[4]; };
 
-__device__ __forceinline__ void window(const float* __restrict__ da, const float* __restrict__ r, int n, int yo,
-                                       int xo, int c, int H, int W, int C, float mean, float inv, float gam,
-                                       float bet, Win& w)
+__device__ __forceinline__ void window4(const f32x4* __restrict__ da4, const f32x4* __restrict__ r4, int n, int yo, int xo, int c4,
+                                        int H, int W, int C4, const f32x4& mean, const f32x4& inv, const f32x4& gam,
+                                        const f32x4& bet, Win4& w)
 {
-    const float* p = r + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
-    w.r[0] = p[0]; w.r[1] = p[C]; w.r[2] = p[(long)W * C]; w.r[3] = p[(long)W * C + C];
-    float best = -INFINITY;
-    int arg = 0;
+    const f32x4* p = r4 + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C4 + c4;
+    w.r[0] = p[0]; w.r[1] = p[C4]; w.r[2] = p[(long)W * C4]; w.r[3] = p[(long)W * C4 + C4];
+    const f32x4 g = da4[(((size_t)n * (H / 2) + yo) * (W / 2) + xo) * C4 + c4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        w.xh[j] = (w.r[j] - mean) * inv;
-        const float y = fmaf(w.xh[j], gam, bet);
-        if (y > best) { best = y; arg = j; }
+    for (int e = 0; e < 4; ++e) {
+        float best = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (w.r[j][e] - mean[e]) * inv[e];
+            w.xh[j][e] = xh;
+            const float y = fmaf(xh, gam[e], bet[e]);
+            if (y > best) { best = y; arg = j; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w.dy[j][e] = (j == arg) ? g[e] : 0.0f;
     }
-    const float g = da[(((size_t)n * (H / 2) + yo) * (W / 2) + xo) * C + c];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w.dy[j] = (j == arg) ? g : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
@@ -234,35 +252,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, long N, int H, int W, int C, int pool,
     float* __restrict__ part /*[G][2][C]*/)
 {
-    __shared__ double red[2][256];
+    __shared__ double red[2][1024];
     const int tid = threadIdx.x;
-    const int c = tid % C, lane = tid / C, L = 256 / C;
-    const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
-    double s0 = 0.0, s1 = 0.0;
+    const int C4 = C >> 2, c4 = tid % C4, lane = tid / C4, L = 256 / C4;
+    const f32x4 mean = *(const f32x4*)(stats + 4 * c4), inv = *(const f32x4*)(stats + C + 4 * c4);
+    const f32x4 gam = *(const f32x4*)(gamma + 4 * c4), bet = *(const f32x4*)(beta + 4 * c4);
+    const f32x4* __restrict__ r4 = (const f32x4*)r;
+    const f32x4* __restrict__ da4 = (const f32x4*)da;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
     if (pool) {
         const int lWo = __ffs(W) - 2, lHo = __ffs(H) - 2;
         const int P = (int)(N << (lWo + lHo));
         const int p0 = (int)(((long)P * blockIdx.x) / gridDim.x), p1 = (int)(((long)P * (blockIdx.x + 1)) / gridDim.x);
-#pragma unroll 2
         for (int p = p0 + lane; p < p1; p += L) {
             const int xo = p & ((1 << lWo) - 1), yo = (p >> lWo) & ((1 << lHo) - 1), n = p >> (lWo + lHo);
-            Win w;
-            window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
+            Win4 w;
+            window4(da4, r4, n, yo, xo, c4, H, W, C4, mean, inv, gam, bet, w);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s0 += w.dy[j]; s1 += (double)w.dy[j] * w.xh[j]; }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += w.dy[j][e]; s1[e] += (double)w.dy[j][e] * w.xh[j][e]; }
         }
     } else {
         const long P = N * H * W;
         const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
-#pragma unroll 8
+#pragma unroll 4
         for (long p = p0 + lane; p < p1; p += L) {
-            const float dy = da[p * C + c];
-            const float xh = (r[p * C + c] - mean) * inv;
-            s0 += dy;
-            s1 += (double)dy * xh;
+            const f32x4 dy = da4[p * C4 + c4];
+            const f32x4 rv = r4[p * C4 + c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (rv[e] - mean[e]) * inv[e];
+                s0[e] += dy[e];
+                s1[e] += (double)dy[e] * xh;
+            }
         }
     }
-    red[0][tid] = s0; red[1][tid] = s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][lane * C + 4 * c4 + e] = s0[e]; red[1][lane * C + 4 * c4 + e] = s1[e]; }
     __syncthreads();
     if (tid < C) {
         double t0 = 0.0, t1 = 0.0;
@@ -303,45 +330,58 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums /*[2][C]*/,
     long N, int H, int W, int C, int pool, float* __restrict__ dz, float* __restrict__ dzsum_part /*[Gz][C]*/)
 {
-    __shared__ double red[256];
+    __shared__ double red[1024];
     const int tid = threadIdx.x;
-    const int c = tid % C, lane = tid / C, L = 256 / C;
-    const float mean = stats[c], inv = stats[C + c], gam = gamma[c], bet = beta[c];
-    const float k = gam * inv, mdy = sums[c], mdx = sums[C + c];
-    double s = 0.0;
+    const int C4 = C >> 2, c4 = tid % C4, lane = tid / C4, L = 256 / C4;
+    const f32x4 mean = *(const f32x4*)(stats + 4 * c4), inv = *(const f32x4*)(stats + C + 4 * c4);
+    const f32x4 gam = *(const f32x4*)(gamma + 4 * c4), bet = *(const f32x4*)(beta + 4 * c4);
+    const f32x4 mdy = *(const f32x4*)(sums + 4 * c4), mdx = *(const f32x4*)(sums + C + 4 * c4);
+    const f32x4 k = gam * inv;
+    const f32x4* __restrict__ r4 = (const f32x4*)r;
+    const f32x4* __restrict__ da4 = (const f32x4*)da;
+    f32x4* __restrict__ dz4 = (f32x4*)dz;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (pool) {
         const int lWo = __ffs(W) - 2, lHo = __ffs(H) - 2;
         const int P = (int)(N << (lWo + lHo));
         const int p0 = (int)(((long)P * blockIdx.x) / gridDim.x), p1 = (int)(((long)P * (blockIdx.x + 1)) / gridDim.x);
-#pragma unroll 2
         for (int p = p0 + lane; p < p1; p += L) {
             const int xo = p & ((1 << lWo) - 1), yo = (p >> lWo) & ((1 << lHo) - 1), n = p >> (lWo + lHo);
-            Win w;
-            window(da, r, n, yo, xo, c, H, W, C, mean, inv, gam, bet, w);
-            float* o = dz + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
-            const long offs[4] = {0, C, (long)W * C, (long)W * C + C};
+            Win4 w;
+            window4(da4, r4, n, yo, xo, c4, H, W, C4, mean, inv, gam, bet, w);
+            f32x4* o = dz4 + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C4 + c4;
+            const long offs[4] = {0, C4, (long)W * C4, (long)W * C4 + C4};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dr = k * (w.dy[j] - mdy - w.xh[j] * mdx);
-                const float v = w.r[j] > 0.0f ? dr : 0.0f;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dr = k[e] * (w.dy[j][e] - mdy[e] - w.xh[j][e] * mdx[e]);
+                    v[e] = w.r[j][e] > 0.0f ? dr : 0.0f;
+                    s[e] += v[e];
+                }
                 o[offs[j]] = v;
-                s += v;
             }
         }
     } else {
         const long P = N * H * W;
         const long p0 = (P * blockIdx.x) / gridDim.x, p1 = (P * (blockIdx.x + 1)) / gridDim.x;
-#pragma unroll 8
+#pragma unroll 4
         for (long p = p0 + lane; p < p1; p += L) {
-            const float rv = r[p * C + c];
-            const float xh = (rv - mean) * inv;
-            const float dr = k * (da[p * C + c] - mdy - xh * mdx);
-            const float v = rv > 0.0f ? dr : 0.0f;
-            dz[p * C + c] = v;
-            s += v;
+            const f32x4 rv = r4[p * C4 + c4], dy = da4[p * C4 + c4];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (rv[e] - mean[e]) * inv[e];
+                const float dr = k[e] * (dy[e] - mdy[e] - xh * mdx[e]);
+                v[e] = rv[e] > 0.0f ? dr : 0.0f;
+                s[e] += v[e];
+            }
+            dz4[p * C4 + c4] = v;
         }
     }
-    red[tid] = s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[lane * C + 4 * c4 + e] = s[e];
     __syncthreads();
     if (tid < C) {
         double t = 0.0;
@@ -714,11 +754,13 @@ __global__ void pack_ep_kernel(const float* __restrict__ bias, const float* __re
 }  // namespace
 
 // ============================================================== launchers
+// the streaming BatchNormalization kernels give a thread four adjacent channels: C a multiple of 4 that divides 1,024
+static bool bn_vec_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0 && 1024 % C == 0; }
 static int stat_grid(long P) { long g = P / 128; if (g < 1) g = 1; if (g > BN_MAX_PARTS) g = BN_MAX_PARTS; return (int)g; }
 
 hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s)
 {
-    if (256 % C) return hipErrorInvalidValue;
+    if (!bn_vec_ok(C)) return hipErrorInvalidValue;
     *G = stat_grid(P);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(*G), dim3(256), 0, s, r, P, C, part);
     return hipGetLastError();
@@ -741,8 +783,8 @@ hipError_t launch_bn_apply(const float* r, int C, const float* gamma, const floa
                            long N, int H, int W, int pool, hipStream_t s)
 {
     const long total = N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * C;
-    if (total >= (1L << 31)) return hipErrorInvalidValue;
-    long g = (total + 1023) / 1024; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    if (total >= (1L << 31) || !bn_vec_ok(C)) return hipErrorInvalidValue;
+    long g = (total / 4 + 511) / 512; if (g > 2048) g = 2048; if (g < 1) g = 1;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, r, C, gamma, beta, stats, a, N, H, W, pool);
     return hipGetLastError();
 }
@@ -765,6 +807,7 @@ hipError_t launch_loss_scalar(const float* errpart, long nparts, long nelem, flo
 hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* stats, const float* gamma, const float* beta,
                                 long N, int H, int W, int C, int pool, float* part, int* G, hipStream_t s)
 {
+    if (!bn_vec_ok(C)) return hipErrorInvalidValue;
     *G = stat_grid(N * (pool ? H / 2 : H) * (pool ? W / 2 : W));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(*G), dim3(256), 0, s, da, r, stats, gamma, beta, N, H, W, C, pool, part);
     return hipGetLastError();
@@ -781,6 +824,7 @@ hipError_t launch_bn_bwd_dz(const float* da, const float* r, const float* stats,
                             const float* sums, long N, int H, int W, int C, int pool, float* dz, float* dzsum_part,
                             int* Gz, hipStream_t s)
 {
+    if (!bn_vec_ok(C)) return hipErrorInvalidValue;
     *Gz = stat_grid(N * (pool ? H / 2 : H) * (pool ? W / 2 : W));
     hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(*Gz), dim3(256), 0, s, da, r, stats, gamma, beta, sums, N, H, W, C, pool, dz,
                        dzsum_part);

@@ -93,8 +93,8 @@ static int describe_trainer(cs_trainer* t, const cs_cae_weights* w)
             // the BatchNormalization / max-pool kernels shared with the reference graph index with shifts and masks
             // (train.hip: "H, W, C are powers of two"): anything else would train on silently wrong statistics
             auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-            if (l < t->n_conv - 1 && (!pow2(t->gh[l]) || !pow2(t->gw[l]) || !pow2(t->ch[l])))
-                return fail(CS_ERR_UNSUPPORTED, "training, conv %d: a %dx%d grid with %d filters -- the BatchNormalization kernels need powers of two",
+            if (l < t->n_conv - 1 && (!pow2(t->gh[l]) || !pow2(t->gw[l]) || !pow2(t->ch[l]) || t->ch[l] < 4 || t->ch[l] > 256))
+                return fail(CS_ERR_UNSUPPORTED, "training, conv %d: a %dx%d grid with %d filters -- the BatchNormalization kernels need powers of two (4 .. 256 filters)",
                             l, t->gh[l], t->gw[l], t->ch[l]);
             // the weight-gradient kernel stages three input rows and one dz row in LDS
             if (wgrad_generic_lds_bytes(t->gw[l], t->cin(l), t->ch[l]) > 160 * 1024)
