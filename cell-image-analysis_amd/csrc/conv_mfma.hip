@@ -514,20 +514,22 @@ using CfgL6 = ConvCfg<32, 32, 64, 32, EPI_BN,      true,   8, 2, STAGE_DB>;   //
 // the same two decoder layers with the upsample folded into 4 phase convs (4/9 of the MACs)
 using CfgL5F = ConvCfg<16, 16, 32, 64, EPI_BN,     true,  16, 2, STAGE_PF, true>;
 using CfgL6F = ConvCfg<32, 32, 64, 32, EPI_BN,     true,   8, 2, STAGE_DB, true>;
-// training forward: conv + bias + ReLU at full conv-grid resolution (BN batch stats come next)
-using CfgF1 = ConvCfg<64, 64,  1, 32, EPI_RELU,    false, 16, 4, STAGE_PF>;
+// training forward: conv + bias + ReLU at full conv-grid resolution (BN batch stats come next).  Strips are SHORT: a fit() batch is
+// 32 cells, and 32 cells x H / SR strips is the whole grid -- at the inference kernels' strip heights half of these launches ran on
+// 32 .. 128 of the 256 CUs
+using CfgF1 = ConvCfg<64, 64,  1, 32, EPI_RELU,    false,  8, 4, STAGE_PF>;
 using CfgF2 = ConvCfg<32, 32, 32, 64, EPI_RELU,    false,  4, 3, STAGE_PF>;
 using CfgF3 = ConvCfg<16, 16, 64, 32, EPI_RELU,    false,  4, 2, STAGE_DB>;
 using CfgF4 = ConvCfg< 8,  8, 32, 32, EPI_RELU,    false,  8, 3, STAGE_PF>;
-using CfgF5 = ConvCfg<16, 16, 32, 64, EPI_RELU,    true,  16, 3, STAGE_PF>;
-using CfgF6 = ConvCfg<32, 32, 64, 32, EPI_RELU,    true,   8, 2, STAGE_DB>;
+using CfgF5 = ConvCfg<16, 16, 32, 64, EPI_RELU,    true,   4, 3, STAGE_PF>;
+using CfgF6 = ConvCfg<32, 32, 64, 32, EPI_RELU,    true,   4, 2, STAGE_DB>;
 // training backward-data: dX = conv(dZ, flipped/transposed kernel) [+ 2x2 sum through an upsample].
 // D<l> is the gradient wrt the input of conv l (1-based): channels swap roles.
-using CfgD7 = ConvCfg<64, 64,  1, 32, EPI_SUMPOOL, false, 16, 4, STAGE_PF>;   // dz7 (1 ch) -> d a6 (32x32x32)
+using CfgD7 = ConvCfg<64, 64,  1, 32, EPI_SUMPOOL, false,  8, 4, STAGE_PF>;   // dz7 (1 ch) -> d a6 (32x32x32)
 using CfgD6 = ConvCfg<32, 32, 32, 64, EPI_SUMPOOL, false,  4, 3, STAGE_PF>;   // dz6 (32 ch) -> d a5 (16x16x64)
 using CfgD5 = ConvCfg<16, 16, 64, 32, EPI_SUMPOOL, false,  4, 2, STAGE_DB>;   // dz5 (64 ch) -> d a4 (8x8x32)
 using CfgD4 = ConvCfg< 8,  8, 32, 32, EPI_PLAIN,   false,  8, 3, STAGE_PF>;   // dz4 -> d p3
-using CfgD3 = ConvCfg<16, 16, 32, 64, EPI_PLAIN,   false,  8, 3, STAGE_PF>;   // dz3 (32 ch) -> d p2 (16x16x64)
+using CfgD3 = ConvCfg<16, 16, 32, 64, EPI_PLAIN,   false,  2, 3, STAGE_PF>;   // dz3 (32 ch) -> d p2 (16x16x64)
 using CfgD2 = ConvCfg<32, 32, 64, 32, EPI_PLAIN,   false,  4, 2, STAGE_DB>;   // dz2 (64 ch) -> d p1 (32x32x32)
 
 template <class C>

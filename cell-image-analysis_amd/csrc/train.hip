@@ -619,6 +619,9 @@ __global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict
 
 // ============================================================== reduce / Adam / packing
 // errpart != NULL: thread 0 also leaves the batch's {loss, mae} in out2 (the order of loss_scalar_kernel).
+// A thread owns four consecutive elements of one descriptor (16-byte loads of every partial: the pass streams ~60 MB of partial
+// sums at batch 32 and sits at the end of the step's critical path); a descriptor's tail shorter than four, or one whose rows are
+// not 16-byte aligned, is summed element by element.  Partials are added in workgroup order: deterministic.
 __global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad,
                                   const float* __restrict__ errpart, long nparts, long nelem, float* __restrict__ out2)
 {
@@ -629,18 +632,28 @@ __global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndes
         out2[0] = (float)(s2 / (double)nelem);
         out2[1] = (float)(s1 / (double)nelem);
     }
-    long base = 0;
+    long base = 0;                                  // in groups of four
     for (int d = 0; d < ndesc; ++d) {
         const ReduceDesc& D = descs[d];
-        if (i < base + D.len) {
-            const long e = i - base;
-            float s = 0.0f;
+        const long ng = (D.len + 3) >> 2;
+        if (i < base + ng) {
+            const long e = (i - base) << 2;
+            const bool vec = e + 4 <= D.len && (D.stride & 3) == 0 && ((((size_t)D.src) | ((size_t)(flat_grad + D.dst))) & 15) == 0;
+            if (vec) {
+                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
-            for (int p = 0; p < D.nparts; ++p) s += D.src[(size_t)p * D.stride + e];
-            flat_grad[D.dst + e] = s;
+                for (int p = 0; p < D.nparts; ++p) s += *(const f32x4*)(D.src + (size_t)p * D.stride + e);
+                *(f32x4*)(flat_grad + D.dst + e) = s;
+            } else {
+                for (long k = e; k < e + 4 && k < D.len; ++k) {
+                    float s = 0.0f;
+                    for (int p = 0; p < D.nparts; ++p) s += D.src[(size_t)p * D.stride + k];
+                    flat_grad[D.dst + k] = s;
+                }
+            }
             return;
         }
-        base += D.len;
+        base += ng;
     }
 }
 
@@ -861,7 +874,9 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s,
                              const float* errpart, long nparts, long nelem, float* out2)
 {
-    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((total_len + 255) / 256)), dim3(256), 0, s, descs_dev, ndesc, flat_grad, errpart, nparts, nelem, out2);
+    // one thread per group of four elements; every descriptor rounds up to whole groups (ndesc extra groups at most)
+    const long groups = total_len / 4 + ndesc + 1;
+    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, s, descs_dev, ndesc, flat_grad, errpart, nparts, nelem, out2);
     return hipGetLastError();
 }
 
