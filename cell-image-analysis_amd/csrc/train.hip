@@ -619,41 +619,54 @@ __global__ __launch_bounds__(256) void wgrad_last_kernel(const float* __restrict
 
 // ============================================================== reduce / Adam / packing
 // errpart != NULL: thread 0 also leaves the batch's {loss, mae} in out2 (the order of loss_scalar_kernel).
-// A thread owns four consecutive elements of one descriptor (16-byte loads of every partial: the pass streams ~60 MB of partial
-// sums at batch 32 and sits at the end of the step's critical path); a descriptor's tail shorter than four, or one whose rows are
-// not 16-byte aligned, is summed element by element.  Partials are added in workgroup order: deterministic.
-__global__ void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad,
-                                  const float* __restrict__ errpart, long nparts, long nelem, float* __restrict__ out2)
+// Four consecutive elements of one descriptor are summed by FOUR threads (16-byte loads; thread q takes the q-th quarter of the
+// partials, the four sums are added in the order ((q0 + q1) + q2) + q3): the pass streams ~60 MB of partial sums at batch 32 at the
+// end of the step's critical path and is bound by the loads it keeps in flight.  A descriptor's tail shorter than four, or one
+// whose rows are not 16-byte aligned, is summed element by element in partial order.  Deterministic either way.
+__global__ __launch_bounds__(256) void reduce_all_kernel(const ReduceDesc* __restrict__ descs, int ndesc, float* __restrict__ flat_grad,
+                                                         const float* __restrict__ errpart, long nparts, long nelem, float* __restrict__ out2)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && errpart) {
+    __shared__ f32x4 red[3][64];
+    const int gl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + gl;
+    if (i == 0 && q == 0 && errpart) {
         double s2 = 0.0, s1 = 0.0;
-        for (long q = 0; q < nparts; ++q) { s2 += errpart[2 * q]; s1 += errpart[2 * q + 1]; }
+        for (long k = 0; k < nparts; ++k) { s2 += errpart[2 * k]; s1 += errpart[2 * k + 1]; }
         out2[0] = (float)(s2 / (double)nelem);
         out2[1] = (float)(s1 / (double)nelem);
     }
     long base = 0;                                  // in groups of four
+    bool vec = false, mine = false;
+    long e = 0;
+    ReduceDesc D{};
     for (int d = 0; d < ndesc; ++d) {
-        const ReduceDesc& D = descs[d];
-        const long ng = (D.len + 3) >> 2;
+        const long ng = (descs[d].len + 3) >> 2;
         if (i < base + ng) {
-            const long e = (i - base) << 2;
-            const bool vec = e + 4 <= D.len && (D.stride & 3) == 0 && ((((size_t)D.src) | ((size_t)(flat_grad + D.dst))) & 15) == 0;
-            if (vec) {
-                f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-                for (int p = 0; p < D.nparts; ++p) s += *(const f32x4*)(D.src + (size_t)p * D.stride + e);
-                *(f32x4*)(flat_grad + D.dst + e) = s;
-            } else {
-                for (long k = e; k < e + 4 && k < D.len; ++k) {
-                    float s = 0.0f;
-                    for (int p = 0; p < D.nparts; ++p) s += D.src[(size_t)p * D.stride + k];
-                    flat_grad[D.dst + k] = s;
-                }
-            }
-            return;
+            D = descs[d];
+            e = (i - base) << 2;
+            mine = true;
+            vec = e + 4 <= D.len && (D.stride & 3) == 0 && ((((size_t)D.src) | ((size_t)(flat_grad + D.dst))) & 15) == 0;
+            break;
         }
         base += ng;
+    }
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (mine && vec) {
+        const int p0 = D.nparts * q / 4, p1 = D.nparts * (q + 1) / 4;
+#pragma unroll 8
+        for (int p = p0; p < p1; ++p) s += *(const f32x4*)(D.src + (size_t)p * D.stride + e);
+    }
+    if (q > 0) red[q - 1][gl] = s;
+    __syncthreads();
+    if (q != 0 || !mine) return;
+    if (vec) {
+        *(f32x4*)(flat_grad + D.dst + e) = ((s + red[0][gl]) + red[1][gl]) + red[2][gl];
+    } else {
+        for (long k = e; k < e + 4 && k < D.len; ++k) {
+            float t = 0.0f;
+            for (int p = 0; p < D.nparts; ++p) t += D.src[(size_t)p * D.stride + k];
+            flat_grad[D.dst + k] = t;
+        }
     }
 }
 
@@ -874,9 +887,9 @@ hipError_t launch_wgrad(int layer, const float* xin, const float* dz, float* par
 hipError_t launch_reduce_all(const ReduceDesc* descs_dev, int ndesc, long total_len, float* flat_grad, hipStream_t s,
                              const float* errpart, long nparts, long nelem, float* out2)
 {
-    // one thread per group of four elements; every descriptor rounds up to whole groups (ndesc extra groups at most)
+    // four threads per group of four elements; every descriptor rounds up to whole groups (ndesc extra groups at most)
     const long groups = total_len / 4 + ndesc + 1;
-    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, s, descs_dev, ndesc, flat_grad, errpart, nparts, nelem, out2);
+    hipLaunchKernelGGL(reduce_all_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(256), 0, s, descs_dev, ndesc, flat_grad, errpart, nparts, nelem, out2);
     return hipGetLastError();
 }
 
