@@ -51,6 +51,8 @@ struct ConvSet {           // one weight set on device, packed for the kernels
 struct GenSet {
     DevBuf w[CS_MAX_CONV], ep[CS_MAX_CONV], wf[CS_MAX_CONV], wx3[CS_MAX_CONV];      // wx3: split-bf16 planes (conv_generic_x3.hip)
     bool folded[CS_MAX_CONV] = {false}, x3[CS_MAX_CONV] = {false};
+    DevBuf wh2[CS_MAX_CONV];            // two fp16 planes (pack_generic_f16x2) of the layers conv_generic_x3_kernel<.., H2> runs
+    float h2_inv[CS_MAX_CONV] = {0};    // 1 / their weight scale; 0 = no fp16 form
 };
 
 // The autoencoder's shape.  ref = the reference graph (64x64, 32-64-32 | 32-64-32-1): tuned kernels;
@@ -363,12 +365,18 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
                 pack_generic_bf16x3(16, cin, cout, wf.data(), pl.data());
                 if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
                 set.x3[l] = true;
+                std::vector<uint16_t> ph(pack_generic_f16x2(16, cin, cout, nullptr, nullptr, nullptr));
+                pack_generic_f16x2(16, cin, cout, wf.data(), ph.data(), &set.h2_inv[l]);
+                if ((rc = upload(set.wh2[l], ph.data(), ph.size() * sizeof(uint16_t)))) return rc;
             }
         } else if (l <= a.n_enc && l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 0)) {
             std::vector<uint16_t> pl(pack_generic_bf16x3(9, cin, cout, nullptr, nullptr));
             pack_generic_bf16x3(9, cin, cout, w->kernel[l], pl.data());
             if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
             set.x3[l] = true;
+            std::vector<uint16_t> ph(pack_generic_f16x2(9, cin, cout, nullptr, nullptr, nullptr));
+            pack_generic_f16x2(9, cin, cout, w->kernel[l], ph.data(), &set.h2_inv[l]);
+            if ((rc = upload(set.wh2[l], ph.data(), ph.size() * sizeof(uint16_t)))) return rc;
         }
         std::vector<float> ep(3 * cout, 0.0f);
         const bool has_bn = w->bn_gamma[l] != nullptr;
@@ -532,9 +540,10 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
             continue;
         }
         if (set.x3[l] && m->bf16x3) {
+            const bool h2 = m->fp16x2 && set.h2_inv[l] != 0.0f;
             LAUNCH(kid, nc,
-                   launch_conv_generic_x3(in, set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), a.ch[l],
-                                          l > a.n_enc, epi, m->stream));
+                   launch_conv_generic_x3(in, h2 ? set.wh2[l].as<uint16_t>() : set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc,
+                                          a.gh[l], a.gw[l], a.cin(l), a.ch[l], l > a.n_enc, epi, m->stream, h2 ? set.h2_inv[l] : 0.0f));
             continue;
         }
         LAUNCH(kid, nc,
@@ -1349,7 +1358,8 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
         if (l < m->arch.n_conv && m->gae.x3[l]) {
             const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
             const double taps = l > m->arch.n_enc ? 4.0 : 9.0;             // folded upsample: 16 (phase, tap) pairs over a quarter of the grid
-            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * taps * (m->arch.cin(l) / 32.0) * 6.0;
+            const bool last = l == m->arch.n_conv - 1;
+            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * taps * (m->arch.cin(l) / 32.0) * ((m->fp16x2 && m->gae.h2_inv[l] != 0.0f && !last) ? 3.0 : 6.0);
         }
     }
     *mfma = v;

@@ -214,8 +214,10 @@ size_t pack_generic_folded(int cin, int cout, const float* hwio, float* dst);
 int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups);
 size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_t* dst);     // returns the number of bf16 values
 hipError_t launch_pack_generic_bf16x3(const float* w, int ntaps, int cin, int cout, uint16_t* dst, hipStream_t stream);   // the same on the device
+// inv_sw != 0: the two-term fp16 split instead (wplanes = pack_generic_f16x2's; per-strip activation scale taken in the kernel)
 hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
-                                  int cout, int ups, int epi, hipStream_t stream);
+                                  int cout, int ups, int epi, hipStream_t stream, float inv_sw = 0.0f);
+size_t pack_generic_f16x2(int ntaps, int cin, int cout, const float* w, uint16_t* dst, float* inv_sw);
 // the 1-filter sigmoid conv behind an UpSampling2D as a cin -> 16 GEMM on bf16 MFMAs + a gather (cin 32 or 64):
 // wplanes = pack_last_bf16x3(cin, pack_generic_folded(cin, 1, hwio, .), .); out = the reconstruction [n][H][W]
 int conv_last_x3_takes(int H, int W, int cin);

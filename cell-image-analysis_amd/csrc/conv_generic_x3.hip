@@ -25,12 +25,38 @@ namespace cs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// ---- H2: the same kernels with the contraction as a TWO-term fp16 split (three products; DESIGN.md 3h, conv_wino_up.hip has the
+// algebra and the hardware facts).  Weights carry a per-layer power-of-two scale (pack_generic_f16x2, inv_sw undoes it); a staged
+// strip is scaled by the power of two that puts ITS max|x| into [2^14, 2^15): the strip is staged as fp32 first (the maximum has to
+// be known before anything is split), then split IN PLACE -- a pixel's fp32 values and its [hi plane | lo plane] are the same
+// 4 cin bytes, and one wave owns a pixel (all of a wave's reads of an instruction precede its writes), so the second pass needs
+// no barrier of its own beyond the one that publishes the maximum.
+__device__ __forceinline__ unsigned int g3h_rowmax(unsigned int m)
+{
+    unsigned int o;
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [1,0,3,2]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);  m = m > o ? m : o;     // quad_perm [2,3,0,1]
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:4
+    o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true); m = m > o ? m : o;     // row_ror:8
+    return m;
+}
+__device__ __forceinline__ void g3h_scale(unsigned int mbits, float& S, float& invS)
+{
+    int E = (int)((mbits >> 23) & 0xffu);
+    E = E < 40 ? 40 : (E > 254 ? 254 : E);
+    S = __builtin_bit_cast(float, (unsigned int)(268 - E) << 23);          // 2^(14 - (E - 127))
+    invS = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23);
+}
+
 struct Gen3Args {
     const float* in;       // stored input [n][Hs][Ws][cin]  (Hs = H/2 for the folded form)
-    const uint16_t* w;     // pack_generic_bf16x3: [step = tap * cin/32 + block][plane][cout_pad][kq][8] bf16
+    const uint16_t* w;     // pack_generic_bf16x3: [step = tap * cin/32 + block][plane][cout_pad][kq][8] bf16 (H2: two fp16 planes)
+    float inv_sw;          // H2: 1 / the weights' scale
     const float* ep;       // [3][cout]
     float* out;
     long n;
@@ -64,9 +90,10 @@ __device__ __forceinline__ f32x4 mac6(const bf16x8 (&a)[3], const bf16x8 (&b)[3]
     return acc;
 }
 
-template <int CIN, int TPW, bool FOLD>
+template <int CIN, int TPW, bool FOLD, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
 {
+    constexpr int NPL = H2 ? 2 : 3;                       // planes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -74,9 +101,12 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
     const int H = g.H, W = g.W, cout = g.cout, SR = g.SR;
     const int Hs = FOLD ? H / 2 : H, Ws = FOLD ? W / 2 : W;
     const int R = FOLD ? SR / 2 + 2 : SR + 2, WP = Ws + 2;
-    constexpr int psb = 6 * CIN + 32;                     // bytes per staged pixel: three planes + pad
+    constexpr int psb = 2 * NPL * CIN + 32;               // bytes per staged pixel: the planes + pad (twice an odd number of 16-byte slots)
     constexpr int PB = 2 * CIN;                           // byte offset of a plane inside the pixel
     constexpr int nkb = CIN / 32;
+    unsigned int* const mxw = (unsigned int*)(smem + (size_t)R * WP * psb);      // H2: the strip's max|x| (one word behind the strip)
+    float us = 1.0f;                                      // H2: 1 / (strip scale x weight scale), applied with the bias
+    if constexpr (H2) { if (tid == 0) *mxw = 0; }
     const int nstrip = H / SR;
     const int cpb = g.nslw * 16, ncb = (cout + cpb - 1) / cpb;
     const int coutp = (cout + 15) & ~15;
@@ -93,7 +123,40 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
         const int ybase = FOLD ? (y0 / 2 - 1) : (y0 - 1);
 
         __syncthreads();                                  // previous item's readers are done
-        {
+        if constexpr (H2) {
+            constexpr int c4n = CIN / 4;
+            float am = 0.0f;
+            for (int e = tid; e < R * WP * c4n; e += 512) {
+                const int c4 = e % c4n, pix = e / c4n;
+                const int r = pix / WP, c = pix - r * WP;
+                const int sy = ybase + r, sx = c - 1;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) v = *(const f32x4*)(src + ((size_t)sy * Ws + sx) * cin + 4 * c4);
+                *(f32x4*)(smem + pix * psb + c4 * 16) = v;                 // fp32 for now: the same bytes become [hi | lo] below
+                const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];   // (scalars: see conv45_bf16x3.hip, h2_absmax4)
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(a2), fabsf(a3))));
+            }
+            const unsigned int m = g3h_rowmax(__builtin_bit_cast(unsigned int, am));
+            if (li == 0) atomicMax(mxw, m);
+            __syncthreads();
+            float S, invS;
+            g3h_scale(*mxw, S, invS);
+            us = invS * g.inv_sw;
+            // in place, one wave per pixel group: lane = (pixel of the group, channel quad)
+            constexpr int ppw = 64 / c4n;                 // pixels per wave and pass (2, 4 or 8)
+            const int c4 = lane % c4n, pl = lane / c4n;
+            for (int p0 = wave * ppw; p0 < R * WP; p0 += 8 * ppw) {
+                const int pix = p0 + pl;
+                if (pix < R * WP) {
+                    char* base = smem + pix * psb;
+                    const f32x4 v = *(const f32x4*)(base + c4 * 16) * S;
+                    const f16x4 hi = __builtin_convertvector(v, f16x4);
+                    const f32x4 rr = v - __builtin_convertvector(hi, f32x4);      // exact in fp32
+                    *(f16x4*)(base + c4 * 8) = hi;
+                    *(f16x4*)(base + PB + c4 * 8) = __builtin_convertvector(rr, f16x4);
+                }
+            }
+        } else {
             constexpr int c4n = CIN / 4;
             for (int e = tid; e < R * WP * c4n; e += 512) {
                 const int c4 = e % c4n, pix = e / c4n;
@@ -110,35 +173,49 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
             }
         }
         __syncthreads();
+        if constexpr (H2) { if (tid == 0) *mxw = 0; }     // read by everyone before the barrier above; the next atomics are behind the next item's first barrier
 
         const int cbase = cb * cpb + slice * 16;
         if (cbase >= cout) continue;                      // wave-uniform: this slice does not exist
         const int co = cbase + li;
         const bool cok = co < cout;
-        const bf16x8* wl = (const bf16x8*)g.w + (size_t)co * 4 + kq;      // + (step * 3 + plane) * wstep
+        // 16-byte fragments of 8 sixteen-bit values (bf16 or fp16: the loads do not care; the MFMA builtin is chosen by H2)
+        const bf16x8* wl = (const bf16x8*)g.w + (size_t)co * 4 + kq;      // + (step * NPL + plane) * wstep
         auto load_b = [&](int step, bf16x8 (&b)[3]) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[p] = wl[((size_t)step * 3 + p) * wstep];
+            for (int p = 0; p < NPL; ++p) b[p] = wl[((size_t)step * NPL + p) * wstep];
         };
         auto read_a = [&](int off, bf16x8 (&a)[3]) {
             a[0] = *(const bf16x8*)(smem + off);
             a[1] = *(const bf16x8*)(smem + off + PB);
-            a[2] = *(const bf16x8*)(smem + off + 2 * PB);
+            if constexpr (!H2) a[2] = *(const bf16x8*)(smem + off + 2 * PB);
         };
-        // one (tap, block) step over the wave's TPW tiles: the next tile's three plane reads are issued ahead of the six
-        // MFMAs of the current one and pinned there (unpinned, the scheduler hoists every tile's reads above the first MFMA)
+        auto mac = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+            if constexpr (H2) {       // planes: [0] hi, [1] lo; one magnitude per instruction
+                const f16x8 ah = __builtin_bit_cast(f16x8, a[0]), al = __builtin_bit_cast(f16x8, a[1]);
+                const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[1]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+                return acc;
+            } else {
+                return mac6(a, b, acc);
+            }
+        };
+        // one (tap, block) step over the wave's TPW tiles: the next tile's plane reads are issued ahead of the MFMAs of the
+        // current one and pinned there (unpinned, the scheduler hoists every tile's reads above the first MFMA)
         auto step_tiles = [&](const int (&base)[TPW], int kb, const bf16x8 (&b)[3], f32x4 (&acc)[TPW]) {
             bf16x8 a[3];
             read_a(base[0] + kb * 64, a);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 bf16x8 an[3] = {a[0], a[1], a[2]};
                 if (t + 1 < TPW) read_a(base[t + 1] + kb * 64, an);
-                acc[t] = mac6(a, b, acc[t]);
+                acc[t] = mac(a, b, acc[t]);
                 a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, H2 ? 3 : 6, 0);
             }
         };
 
@@ -178,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
                 const float bias = g.epi == GEN_EPI_PLAIN ? 0.0f : g.ep[co];
                 if (g.epi == GEN_EPI_BN_POOL) {
                     const float bns = g.ep[cout + co], bnt = g.ep[2 * cout + co];
-                    auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
+                    auto post = [&](float v) { v = fmaf(v, us, bias); v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };     // us = 1 unless H2
                     float* o = g.out + ((size_t)cell * (H / 2) + y0 / 2) * (W / 2) * cout + co;
 #pragma unroll
                     for (int i = 0; i < PPW; ++i)
@@ -196,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int py = tpy[t >> 1] + (t & 1), px = tpx[t >> 1] + 4 * kq + r;
-                            const float z = acc[t][r] + bias;
+                            const float z = fmaf(acc[t][r], us, bias);
                             float v;
                             if (g.epi == GEN_EPI_BN) v = fmaf(fmaxf(z, 0.0f), bns, bnt);
                             else if (g.epi == GEN_EPI_RELU) v = fmaxf(z, 0.0f);
@@ -245,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_generic_x3_kernel(Gen3Args g)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int ys = t / TPRs, xs = (t % TPRs) * 16 + 4 * kq + r;
-                            const float z = fmaxf(acc[t][r] + bias, 0.0f);
+                            const float z = fmaxf(fmaf(acc[t][r], us, bias), 0.0f);
                             o[((size_t)(2 * ys) * W + 2 * xs) * cout] = g.epi == GEN_EPI_BN ? fmaf(z, bns, bnt) : z;
                         }
                 }
@@ -441,8 +518,30 @@ size_t pack_generic_bf16x3(int ntaps, int cin, int cout, const float* w, uint16_
     return total;
 }
 
+// the same layout with TWO fp16 planes of S_w w (S_w: the power of two that puts max|w| of the layer into [2^14, 2^15)):
+// dst: [step][plane 2][cout_pad][kq][8]; *inv_sw = 1 / S_w
+size_t pack_generic_f16x2(int ntaps, int cin, int cout, const float* w, uint16_t* dst, float* inv_sw)
+{
+    const int coutp = (cout + 15) & ~15, nkb = cin / 32;
+    const size_t total = (size_t)ntaps * nkb * 2 * coutp * 32;
+    if (!dst) return total;
+    const float S = f16x2_weight_scale(w, (size_t)ntaps * cin * cout);
+    *inv_sw = 1.0f / S;
+    for (int t = 0; t < ntaps; ++t)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int co = 0; co < coutp; ++co)
+                for (int k = 0; k < 32; ++k) {
+                    const float v = co < cout ? w[((size_t)t * cin + 32 * kb + k) * cout + co] : 0.0f;
+                    uint16_t pl[2];
+                    f16x2_split(v, S, pl[0], pl[1]);
+                    for (int p = 0; p < 2; ++p) dst[((((size_t)t * nkb + kb) * 2 + p) * coutp + co) * 32 + k] = pl[p];
+                }
+    return total;
+}
+
+// inv_sw != 0: wplanes = pack_generic_f16x2's planes, the contraction as a two-term fp16 split (same plans, a smaller strip)
 hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, const float* ep, float* out, int64_t n, int H, int W, int cin,
-                                  int cout, int ups, int epi, hipStream_t stream)
+                                  int cout, int ups, int epi, hipStream_t stream, float inv_sw)
 {
     if (n <= 0) return hipSuccess;
     int SR = 0, nmg = 0, nslw = 0, tpw = 0;
@@ -454,15 +553,25 @@ hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, cons
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     Gen3Args a;
     a.in = in; a.w = wplanes; a.ep = ep; a.out = out; a.n = n; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.epi = epi;
-    a.SR = SR; a.nmg = nmg; a.nslw = nslw;
+    a.SR = SR; a.nmg = nmg; a.nslw = nslw; a.inv_sw = inv_sw;
+    const bool h2 = inv_sw != 0.0f;
+    if (h2) {   // two planes per pixel + the word that collects the strip's maximum
+        const int Ws = ups ? W / 2 : W, R = ups ? SR / 2 + 2 : SR + 2;
+        lds = (size_t)R * (Ws + 2) * (4 * cin + 32) + 16;
+    }
     const long items = (long)n * (H / SR) * ((cout + nslw * 16 - 1) / (nslw * 16));
     const int per_cu = (tpw <= 8 && lds <= 76 * 1024) ? 2 : 1;
     const unsigned grid = (unsigned)(items < (long)cus * per_cu ? items : (long)cus * per_cu);
     hipError_t e = hipSuccess;
 #define X3_LAUNCH(C, T, F)                                                                                                          \
     do {                                                                                                                            \
-        e = hipFuncSetAttribute((const void*)conv_generic_x3_kernel<C, T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((conv_generic_x3_kernel<C, T, F>), dim3(grid), dim3(512), lds, stream, a);           \
+        if (h2) {                                                                                                                   \
+            e = hipFuncSetAttribute((const void*)conv_generic_x3_kernel<C, T, F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((conv_generic_x3_kernel<C, T, F, true>), dim3(grid), dim3(512), lds, stream, a); \
+        } else {                                                                                                                    \
+            e = hipFuncSetAttribute((const void*)conv_generic_x3_kernel<C, T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e == hipSuccess) hipLaunchKernelGGL((conv_generic_x3_kernel<C, T, F>), dim3(grid), dim3(512), lds, stream, a);       \
+        }                                                                                                                           \
     } while (0)
 #define X3_TPW(C, F)                                       \
     switch (tpw) {                                         \

@@ -95,6 +95,40 @@ def test_rectangular_variant_with_odd_channel_counts():
         e.close()
 
 
+@pytest.mark.parametrize("scale", [1.0, 255.0, 1.0e-3])
+def test_generic_fp16_split_convs_scale_with_the_data_and_match_the_bf16_form(scale, monkeypatch):
+    """The run-time-shaped convs take their contraction as a two-term fp16 split by default (conv_generic_x3_kernel<.., H2>: a strip is
+    staged as fp32, its own max|x| fixes a power-of-two scale, then it is split in place), as the three-term bf16 split behind
+    CS_NO_FP16X2=1.  Every layer of both against the fp64 oracle at the unchanged tolerance, for crops in [0, 1], raw 8-bit values and
+    values of 1e-3 (fp16's range is 2^-24 .. 65,504: an unscaled split would overflow or vanish); half the matrix instructions; and a
+    cell's result does not depend on what it is screened with."""
+    hw = (64, 128)
+    w = synth.random_cae(seed=13, hw=hw, channels=(32, 64, 128, 128, 64, 32, 1), n_enc=3)
+    x = (np.concatenate([synth.synth_crops(5, 0, 3, hw=hw), synth.blob_crops(6, 3, hw=hw)]) * np.float32(scale)).astype(np.float32)
+    ref = oracle.cae_forward(w, x, acc64=True, layers=True)["layers"]
+    names = ["conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool", "conv4_relu_bn", "conv5_up_relu_bn", "conv6_up_relu_bn"]
+
+    def run():
+        e = Engine.from_weights(w)
+        prof = e.profile()
+        got = [e.layer_output(x, l) for l in range(6)]
+        alone = e.layer_output(x[2:3], 5)
+        e.close()
+        return got, {n: prof[n]["bf16_mfma_per_cell"] for n in names}, alone
+
+    got_h, n_h, alone = run()
+    monkeypatch.setenv("CS_NO_FP16X2", "1")
+    got_b, n_b, _ = run()
+    for l in range(1, 6):
+        assert n_h[names[l]] * 2 == n_b[names[l]] > 0, (l, n_h, n_b)
+    for l in range(6):
+        want = ref[l].reshape(got_h[l].shape)
+        H.assert_close_scaled(got_h[l], want, H.TOL_FEATURES, f"layer {l}, fp16 split, input scale {scale:g}")
+        H.assert_close_scaled(got_b[l], want, H.TOL_FEATURES, f"layer {l}, bf16 split, input scale {scale:g}")
+    assert not np.array_equal(got_h[5], got_b[5])          # the two forms really are different kernels
+    assert np.array_equal(alone[0], got_h[5][2])
+
+
 @pytest.mark.parametrize("channels,expect", [((32, 64, 128, 128, 64, 32, 1), {1, 2, 3, 4, 5}), ((32, 40, 32, 32, 40, 32, 1), {1, 4})])
 def test_split_bf16_convs_against_the_fp32_kernels_and_the_oracle(channels, expect, monkeypatch):
     """csrc/conv_generic_x3.hip: the MFMA convs of a non-reference architecture take the fp32 contraction on the bf16 matrix
