@@ -644,7 +644,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (results in the fp32 error class; the contractions run as split 16-bit products on the matrix pipe, fp32 accumulate: "
-                     "conv2/4/5/6 as 2 fp16 terms x 3 products with exact power-of-two scales, conv1/conv3/PCA as 3 bf16 terms x 6 products; "
+                     "conv1..conv6 as 2 fp16 terms x 3 products with exact power-of-two scales from each cell's own data, the PCA GEMM as 3 bf16 terms x 6 products, "
+                     "conv7's 32 -> 16 channel contraction on fp32 MFMAs; "
                      "SVM fp64; exact_fp32 = the fp32-MFMA form)",
             "data": "synthetic",
             "config": {"workload": (("BASELINE.json configs[2]: screening inference, %d synthetic 64x64 crops on one GPU, resident in HBM, " % args.cells) if world == 1 else
