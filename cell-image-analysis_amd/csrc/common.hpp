@@ -170,7 +170,8 @@ constexpr int BN_MAX_PARTS = 1024;     // workgroups per BatchNorm statistics / 
                                        // tensors with ~1 element in flight per thread, so they need every SIMD several waves deep
 struct ReduceDesc { long dst; long len; const float* src; int nparts; long stride; };
 hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag, const float* bias,
-                                 float* relu_out, int64_t n_cells, hipStream_t stream);
+                                 float* relu_out, int64_t n_cells, hipStream_t stream, float* stats_part = nullptr,
+                                 int* stats_parts = nullptr);
 hipError_t launch_conv_dgrad(int layer, const float* dz, const float* wfrag_t, float* dx, int64_t n_cells,
                              hipStream_t stream);
 hipError_t launch_bn_stats(const float* r, long P, int C, float* part, int* G, hipStream_t s);

@@ -162,10 +162,15 @@ struct Stager {
     }
 };
 
+// stats_part (EPI_RELU only, may be NULL): the training forward also leaves, per workgroup, {count, mean, M2} of every channel of
+// the relu outputs it wrote -- [gridDim.x][3][COUT] floats, the partials bn_stats_final_kernel merges (train.hip) -- so that
+// BatchNormalization's statistics need no pass of their own over the tensor.  A lane adds the 8 values of a tile pair and their
+// squares in fp32 and those into double accumulators; the 4 pixel-quad lanes of a channel are added by shuffles, the waves of a
+// slice through LDS in wave order: deterministic.
 template <class C>
 __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wfrag, const float* __restrict__ ep,
-    float* __restrict__ out, long n_cells)
+    float* __restrict__ out, long n_cells, float* __restrict__ stats_part)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Stager<C>;
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         }
     }
 
+    // EPI_RELU + stats_part: this lane's running {sum, sum of squares} live in LDS behind the strip(s) (two doubles per thread:
+    // the register file of the cin = 64 layers is full), its count follows from the items the workgroup has walked
+    double* const st_acc = (double*)(smem + C::LDS_BYTES) + 2 * threadIdx.x;
+    int st_items = 0;
+    if constexpr (C::EPI == EPI_RELU) { if (stats_part) { st_acc[0] = 0.0; st_acc[1] = 0.0; } }
     const long total = n_cells * C::NSTRIP;
     const long first = blockIdx.x;
     if (first >= total) return;
@@ -480,13 +490,24 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
                 pooled_store(acc0, acc1, o);
             } else {
+                float ps = 0.0f, pq = 0.0f;              // the pair's 8 values in fp32, then into the double accumulators
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int qy, qx;
                     tile_pixel<C>(t0, 4 * kq + r, qy, qx);
-                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = post(acc0[r]);
+                    const float v0 = post(acc0[r]);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = v0;
                     tile_pixel<C>(t1, 4 * kq + r, qy, qx);
-                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = post(acc1[r]);
+                    const float v1 = post(acc1[r]);
+                    out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = v1;
+                    if constexpr (C::EPI == EPI_RELU) {
+                        ps += v0 + v1;
+                        pq = fmaf(v0, v0, pq);
+                        pq = fmaf(v1, v1, pq);
+                    }
+                }
+                if constexpr (C::EPI == EPI_RELU) {
+                    if (stats_part) { st_acc[0] += (double)ps; st_acc[1] += (double)pq; }
                 }
             }
 
@@ -500,6 +521,36 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
         }   // !FOLD
         __syncthreads();  // all reads of this strip done; (STAGE_DB) next strip complete in the other buffer
         buf ^= 1;
+        ++st_items;
+    }
+    if constexpr (C::EPI == EPI_RELU) {
+        if (stats_part) {
+            // lanes kq = 0..3 of a channel, then the NMG waves of the slice (wave = mg * NSL + nsl) in order
+            double st_s = st_acc[0], st_q = st_acc[1];
+            st_s += __shfl_xor(st_s, 16); st_s += __shfl_xor(st_s, 32);
+            st_q += __shfl_xor(st_q, 16); st_q += __shfl_xor(st_q, 32);
+            double* red = (double*)smem;                   // [wave 4][2][16]; the strip is dead (barrier above)
+            if (kq == 0) { red[(wave * 2 + 0) * 16 + li] = st_s; red[(wave * 2 + 1) * 16 + li] = st_q; }
+            __syncthreads();
+            if (tid < C::COUT) {
+                const int sl = tid >> 4, l16 = tid & 15;
+                double a = 0.0, q = 0.0;
+#pragma unroll
+                for (int g = 0; g < C::NMG; ++g) {
+                    const int w = g * C::NSL + sl;
+                    a += red[(w * 2 + 0) * 16 + l16]; q += red[(w * 2 + 1) * 16 + l16];
+                }
+                // a lane writes 8 values per tile pair, PPW pairs per item; 4 lanes per channel, NMG waves per slice
+                const double n = (double)st_items * (8.0 * C::PPW * 4 * C::NMG);
+                const double mu = a / n;
+                double m2 = q - a * mu;
+                m2 = m2 > 0.0 ? m2 : 0.0;
+                float* o = stats_part + (size_t)blockIdx.x * 3 * C::COUT;
+                o[tid] = (float)n;
+                o[C::COUT + tid] = (float)mu;
+                o[2 * C::COUT + tid] = (float)m2;
+            }
+        }
     }
 }
 
@@ -532,9 +583,12 @@ using CfgD4 = ConvCfg< 8,  8, 32, 32, EPI_PLAIN,   false,  8, 3, STAGE_PF>;   //
 using CfgD3 = ConvCfg<16, 16, 32, 64, EPI_PLAIN,   false,  2, 3, STAGE_PF>;   // dz3 (32 ch) -> d p2 (16x16x64)
 using CfgD2 = ConvCfg<32, 32, 64, 32, EPI_PLAIN,   false,  4, 2, STAGE_DB>;   // dz2 (64 ch) -> d p1 (32x32x32)
 
+// the training-forward kernels keep two doubles per thread behind the strip(s) (the statistics accumulators)
+template <class C> constexpr int kStatsLds = (C::EPI == EPI_RELU) ? 256 * 16 : 0;
+
 template <class C>
 static hipError_t launch_cfg(const float* in, const float* wfrag, const float* ep, float* out,
-                             int64_t n_cells, hipStream_t stream)
+                             int64_t n_cells, hipStream_t stream, float* stats_part = nullptr, int* stats_parts = nullptr)
 {
     // Persistent grid = exactly the number of workgroups the chip holds at once (CUs x resident
     // workgroups per CU for this kernel's registers and LDS): a larger grid would queue the
@@ -542,12 +596,12 @@ static hipError_t launch_cfg(const float* in, const float* wfrag, const float* e
     static int resident = 0, cus = 0;
     if (!resident) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<C>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + kStatsLds<C>);
         if (e != hipSuccess) return e;
         int dev = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_mfma_kernel<C>, 256, C::LDS_BYTES);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_mfma_kernel<C>, 256, C::LDS_BYTES + kStatsLds<C>);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         resident = cus * per_cu;
@@ -555,8 +609,9 @@ static hipError_t launch_cfg(const float* in, const float* wfrag, const float* e
     const long total = (long)n_cells * C::NSTRIP;
     if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, in, wfrag, ep,
-                       out, (long)n_cells);
+    if (stats_parts) *stats_parts = (int)grid;
+    hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES + kStatsLds<C>, stream, in, wfrag, ep,
+                       out, (long)n_cells, stats_part);
     return hipGetLastError();
 }
 
@@ -576,16 +631,18 @@ hipError_t launch_conv_mfma(int layer, const float* in, const float* wfrag, cons
     }
 }
 
+// stats_part / stats_parts (optional): the kernel also leaves its workgroups' {count, mean, M2} per channel of what it wrote in
+// stats_part [*stats_parts][3][cout] -- the input of launch_bn_stats_final, in place of launch_bn_stats' pass over the tensor
 hipError_t launch_conv_train_fwd(int layer, const float* in, const float* wfrag, const float* bias,
-                                 float* relu_out, int64_t n_cells, hipStream_t stream)
+                                 float* relu_out, int64_t n_cells, hipStream_t stream, float* stats_part, int* stats_parts)
 {
     switch (layer) {
-        case 0: return launch_cfg<CfgF1>(in, wfrag, bias, relu_out, n_cells, stream);
-        case 1: return launch_cfg<CfgF2>(in, wfrag, bias, relu_out, n_cells, stream);
-        case 2: return launch_cfg<CfgF3>(in, wfrag, bias, relu_out, n_cells, stream);
-        case 3: return launch_cfg<CfgF4>(in, wfrag, bias, relu_out, n_cells, stream);
-        case 4: return launch_cfg<CfgF5>(in, wfrag, bias, relu_out, n_cells, stream);
-        case 5: return launch_cfg<CfgF6>(in, wfrag, bias, relu_out, n_cells, stream);
+        case 0: return launch_cfg<CfgF1>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
+        case 1: return launch_cfg<CfgF2>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
+        case 2: return launch_cfg<CfgF3>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
+        case 3: return launch_cfg<CfgF4>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
+        case 4: return launch_cfg<CfgF5>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
+        case 5: return launch_cfg<CfgF6>(in, wfrag, bias, relu_out, n_cells, stream, stats_part, stats_parts);
         default: return hipErrorInvalidValue;
     }
 }

@@ -300,9 +300,9 @@ static int fb_enqueue(cs_trainer* t, int64_t B)
     for (int l = 0; l < 6; ++l) {
         const int C = kRefChannels[l], Hc = kConvGrid[l], pool = l < kNEnc;
         const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
-        LCHK(launch_conv_train_fwd(l, in, t->wf[l].as<float>(), P + t->off_b[l], t->r[l].as<float>(), B, s));
+        // the conv leaves its workgroups' {count, mean, M2} per channel beside the tensor: no statistics pass over r
         int G1 = 0;
-        LCHK(launch_bn_stats(t->r[l].as<float>(), (long)B * Hc * Hc, C, t->part_stats.as<float>(), &G1, s));
+        LCHK(launch_conv_train_fwd(l, in, t->wf[l].as<float>(), P + t->off_b[l], t->r[l].as<float>(), B, s, t->part_stats.as<float>(), &G1));
         if (t->sync_fn) {
             // the local partials -> ONE {count, mean, M2} triple per channel in this rank's slot, all-gather, and the final merge
             // runs over the ranks' triples: the statistics (and the moving averages) of the whole batch, identical on every rank
