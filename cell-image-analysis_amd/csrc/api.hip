@@ -90,6 +90,7 @@ struct cs_model {
     bool x3conv3 = getenv("CS_NO_BF16X3_CONV3") == nullptr; // A/B knob: conv3's Winograd contraction on the fp32 matrix instructions
     bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
     bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
+    bool fuse45 = getenv("CS_NO_FUSE45") == nullptr;         // A/B knob: conv4 and conv5 as two kernels (a4 through HBM)
     bool small_split = getenv("CS_NO_SMALL_SPLIT") == nullptr; // A/B knob: small calls (<= DET_SPLIT_MAX_CELLS) run the detector tail's ranges side by side
     bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
     bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
@@ -576,8 +577,17 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
         int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
         if (rc) return rc;
     }
+    // conv4 + conv5 as one kernel when a4 itself is not asked for (conv5 is bound by its HBM writes: conv4 rides under them)
+    const bool fused45 = m->fuse45 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv4 && m->h2conv5 && first <= 3 && last >= 4;
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
+        if (l == 3 && fused45) {
+            LAUNCH(K_CONV5, nc,
+                   launch_conv45_h2(in, set.c4h2.as<uint16_t>(), set.c4h2_inv, set.ep[3].as<float>(), set.c5h2.as<uint16_t>(), set.c5h2_inv,
+                                    set.ep[4].as<float>(), m->act[4].as<float>(), nc, m->stream));
+            ++l;            // conv5 is done too
+            continue;
+        }
         if (l == 4 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv5) {
             LAUNCH(K_CONV5, nc,
                    launch_conv5_h2(in, set.c5h2.as<uint16_t>(), set.c5h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
@@ -1351,6 +1361,7 @@ int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
             v = 66 * 8 * ((m->fp16x2 && m->h2conv2 && m->h2conv1) ? 2 : 3)                   // (conv1 as an fp16 split: 2 MFMAs)
                 + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
         if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * ((m->fp16x2 && m->h2conv5) ? 3 : 6);   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 | 3 products
+        if (k == K_CONV5 && m->fuse45 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv4 && m->h2conv5) v += 4 * 2 * 9 * 3;   // + conv4 inside the fused conv4 + conv5 kernel
         if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6)          // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6 (bf16 split) or 3 (fp16 split)
             v = 4.0 * 16 * 2 * 4 * 2 * ((m->fp16x2 && m->h2conv6) ? 3 : 6);
     } else if (k <= K_CONV6 && m->bf16x3) {

@@ -125,6 +125,9 @@ size_t pack_conv5_bf16x3(const float* weff, uint16_t* dst);
 hipError_t launch_conv4_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
 size_t pack_conv4_f16x2(const float* hwio, uint16_t* dst, float* inv_sw);
 hipError_t launch_conv5_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
+// conv4 + conv5 as one kernel (a4 stays in LDS): in = p3, out = a5; the two layers' own packed planes and epilogue tables
+hipError_t launch_conv45_h2(const float* in, const uint16_t* w4, float inv_sw4, const float* ep4, const uint16_t* w5, float inv_sw5,
+                            const float* ep5, float* out, int64_t n_cells, hipStream_t stream);
 size_t pack_conv5_f16x2(const float* weff, uint16_t* dst, float* inv_sw);
 // conv5 (layer 4) / conv6 (layer 5), the upsample-fed decoder convs, as four Winograd F(2x2,2x2) phase convs: conv_wino_up.hip
 hipError_t launch_conv_wino_up(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,

@@ -477,6 +477,163 @@ __global__ __launch_bounds__(512, 2) void conv5_h2_kernel(const float* __restric
     }
 }
 
+// ---- conv4 + conv5 in one kernel (fp16 split): a4 never leaves LDS ----------------------------------------------------------------
+// conv5 writes a5 at what HBM takes (65.5 KB per cell at ~5 TB/s: profiles/r03_b_pmc_traffic.json), so conv4's 216 MFMAs per cell and
+// its two extra barriers ride under that for free, and the a4 round trip (8 KB out, 8 KB in) and a launch per chunk go.  A workgroup is
+// conv5_h2_kernel's (8 waves = 4 output phases x 2 filter halves for conv5; for conv4 wave = (16-pixel tile, 16-filter slice)); p3 is
+// staged as conv4_h2_kernel stages it, conv4's weights sit in LDS (37 KB, one 16-byte read per MFMA operand: registers are conv5's), its
+// output goes through the same per-cell maximum -> power-of-two scale -> [hi | lo] planes as a staged input would, into a second image.
+constexpr int F45_OFF_A = 2 * PLANE;                       // a4 planes
+constexpr int F45_OFF_W4 = 4 * PLANE;                      // conv4 weights: pack_conv4_f16x2's [slice 2][tap 9][plane 2][lane 64][8]
+constexpr int F45_W4_BYTES = 2 * 9 * 2 * 64 * 16;
+constexpr int F45_OFF_MAX = F45_OFF_W4 + F45_W4_BYTES;     // four words: p3 maxima [2], a4 maxima [2] (each alternating)
+constexpr int F45_LDS_BYTES = F45_OFF_MAX + 16;
+static_assert(2 * F45_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(512, 2) void conv45_h2_kernel(const float* __restrict__ in /* p3 */, const f16x8* __restrict__ w4frag,
+                                                           const float* __restrict__ ep4, float inv_sw4, const f16x8* __restrict__ w5frag,
+                                                           const float* __restrict__ ep5, float inv_sw5, float* __restrict__ out /* a5 */,
+                                                           long n_cells)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* const mxw = (unsigned int*)(smem + F45_OFF_MAX);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    // conv5 roles
+    const int ph = wave >> 1, pa = ph >> 1, pb = ph & 1;      // output phase (a,b)
+    const int sp = wave & 1;                                  // filters 32 sp .. 32 sp + 31
+    // conv4 roles
+    const int slice4 = wave & 1, tile4 = wave >> 1;           // filters 16 slice4 .. +15; pixels 16 tile4 .. +15 (rows 2 tile4, 2 tile4 + 1)
+
+    f16x8 B[4][2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) B[t][k][p] = w5frag[(((wave * 4 + t) * 2 + k) * 2 + p) * 64 + lane];
+    float bias[2], bns[2], bnt[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int co = (2 * sp + k) * 16 + li;
+        bias[k] = ep5[co]; bns[k] = ep5[C5_OUT + co]; bnt[k] = ep5[2 * C5_OUT + co];
+    }
+    const int co4 = slice4 * 16 + li;
+    const float bias4 = ep4[co4], bns4 = ep4[CH + co4], bnt4 = ep4[2 * CH + co4];
+
+    for (int i = tid; i < F45_LDS_BYTES / 16; i += 512) *(f32x4*)(smem + i * 16) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    for (int i = tid; i < F45_W4_BYTES / 16; i += 512) *(f16x8*)(smem + F45_OFF_W4 + i * 16) = w4frag[i];
+
+    long cell = blockIdx.x;
+    if (cell >= n_cells) return;
+    f32x4 stg = *(const f32x4*)(in + (size_t)cell * (G * G * CH) + tid * 4);
+    {
+        unsigned int mx = 0;
+        h2_absmax4(stg, mx);
+        mx = h2_rowmax(mx);
+        if (li == 0) atomicMax(&mxw[0], mx);
+    }
+    __syncthreads();
+    float S3, invS3;
+    h2_scale(mxw[0], S3, invS3);
+    const int woff = ((tid >> 6) + 1) * ROWB + (((tid >> 3) & 7) + 1) * PXB + (tid & 7) * 8;      // this thread's p3 element
+    const int abase4 = (2 * tile4 + (li >> 3)) * ROWB + (li & 7) * PXB + kq * 16;               // conv4 A operand (image P)
+    const char* const w4l = smem + F45_OFF_W4 + (size_t)slice4 * 9 * 2 * 64 * 16 + lane * 16;    // + (tap * 2 + plane) * 1024
+    const int abase5 = F45_OFF_A + ((li >> 3) + pa) * ROWB + ((li & 7) + pb) * PXB + kq * 16;  // conv5 A operand (image A)
+
+    for (int it = 0; cell < n_cells; cell += gridDim.x, ++it) {
+        h2_split_store(smem + woff, stg, S3);
+        __syncthreads();                                   // image P complete (and, first cell, conv4's weights)
+        if (tid == 0) mxw[it & 1] = 0;
+        const long ncell = cell + gridDim.x;
+        if (ncell < n_cells) stg = *(const f32x4*)(in + (size_t)ncell * (G * G * CH) + tid * 4);     // in flight during both MFMA phases
+
+        // ---- conv4: one (tile, slice) per wave
+        f32x4 a4v;
+        {
+            f32x4 hi = {0.0f, 0.0f, 0.0f, 0.0f}, lo = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const char* a = smem + abase4 + (tap / 3) * ROWB + (tap % 3) * PXB;
+                const f16x8 a1 = *(const f16x8*)a;
+                const f16x8 a2 = *(const f16x8*)(a + PLANE);
+                const f16x8 bh = *(const f16x8*)(w4l + (tap * 2 + 0) * 1024), bl = *(const f16x8*)(w4l + (tap * 2 + 1) * 1024);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bh, lo, 0, 0, 0);
+            }
+            const float us4 = invS3 * inv_sw4;
+            float am = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(fmaf(hi[r] + lo[r], us4, bias4), 0.0f);
+                a4v[r] = fmaf(v, bns4, bnt4);
+                am = fmaxf(am, fabsf(a4v[r]));
+            }
+            const unsigned int m = h2_rowmax(__builtin_bit_cast(unsigned int, am));
+            if (li == 0) atomicMax(&mxw[2 + (it & 1)], m);
+        }
+        __syncthreads();                                   // a4's maximum complete; image P fully read
+        float S4, invS4;
+        h2_scale(mxw[2 + (it & 1)], S4, invS4);
+        {   // D row 4 kq + r = pixel 16 tile4 + 4 kq + r, column = channel co4: [hi | lo] into image A
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 16 * tile4 + 4 * kq + r;
+                char* d = smem + F45_OFF_A + ((p >> 3) + 1) * ROWB + ((p & 7) + 1) * PXB + co4 * 2;
+                const float v = a4v[r] * S4;
+                const _Float16 h = (_Float16)v;
+                *(_Float16*)d = h;
+                *(_Float16*)(d + PLANE) = (_Float16)(v - (float)h);
+            }
+        }
+        __syncthreads();                                   // image A complete
+        if (tid == 0) mxw[2 + (it & 1)] = 0;              // read by everyone before the barrier above; next used two cells on
+
+        // ---- conv5 (conv5_h2_kernel's body on image A)
+        const float unscale = invS4 * inv_sw5;
+        float* obase = out + (((size_t)cell * (2 * G) + pa) * (2 * G) + pb) * C5_OUT + (2 * sp) * 16 + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 ah[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+            f32x4 al[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const char* a = smem + abase5 + t * (2 * ROWB) + (tap >> 1) * ROWB + (tap & 1) * PXB;
+                const f16x8 a1 = *(const f16x8*)a;
+                const f16x8 a2 = *(const f16x8*)(a + PLANE);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    al[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, B[tap][k][1], al[k], 0, 0, 0);
+                    ah[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, B[tap][k][0], ah[k], 0, 0, 0);
+                    al[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, B[tap][k][0], al[k], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * kq + r, ys = 2 * t + (i >> 3), xs = i & 7;
+                float* o = obase + ((size_t)(2 * ys) * (2 * G) + 2 * xs) * C5_OUT;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float v = fmaxf(fmaf(ah[k][r] + al[k][r], unscale, bias[k]), 0.0f);
+                    o[16 * k] = fmaf(v, bns[k], bnt[k]);
+                }
+            }
+        }
+        if (ncell < n_cells) {
+            unsigned int mx = 0;
+            h2_absmax4(stg, mx);
+            mx = h2_rowmax(mx);
+            if (li == 0) atomicMax(&mxw[(it + 1) & 1], mx);
+        }
+        __syncthreads();           // every wave is done reading image A; the next cell's p3 maximum is complete
+        h2_scale(mxw[(it + 1) & 1], S3, invS3);
+    }
+}
+
 uint16_t bf16_rne(float x)
 {
     uint32_t u;
@@ -655,6 +812,24 @@ hipError_t launch_conv5_h2(const float* in, const uint16_t* wfrag, float inv_sw,
     const long grid = n_cells < resident ? n_cells : resident;
     hipLaunchKernelGGL(conv5_h2_kernel, dim3((unsigned)grid), dim3(512), H2_LDS_BYTES, stream, in, (const f16x8*)wfrag, ep, out,
                        (long)n_cells, inv_sw);
+    return hipGetLastError();
+}
+
+// conv4 + conv5 as one kernel: w4 = pack_conv4_f16x2's planes, w5 = pack_conv5_f16x2's; in = p3 [n][8][8][32], out = a5 [n][16][16][64]
+hipError_t launch_conv45_h2(const float* in, const uint16_t* w4, float inv_sw4, const float* ep4, const uint16_t* w5, float inv_sw5,
+                            const float* ep5, float* out, int64_t n_cells, hipStream_t stream)
+{
+    if (n_cells <= 0) return hipSuccess;
+    static int resident = 0;
+    if (!resident) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv45_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F45_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = resident_grid(conv45_h2_kernel, 512, F45_LDS_BYTES, resident);
+        if (e != hipSuccess) return e;
+    }
+    const long grid = n_cells < resident ? n_cells : resident;
+    hipLaunchKernelGGL(conv45_h2_kernel, dim3((unsigned)grid), dim3(512), F45_LDS_BYTES, stream, in, (const f16x8*)w4, ep4, inv_sw4,
+                       (const f16x8*)w5, ep5, inv_sw5, out, (long)n_cells);
     return hipGetLastError();
 }
 

@@ -148,6 +148,29 @@ def test_fp16_split_results_do_not_depend_on_the_batch(weights, det):
         e.close()
 
 
+@pytest.mark.parametrize("scale", [1.0, 255.0])
+def test_fused_conv4_conv5_equals_the_two_kernels(weights, scale, monkeypatch):
+    """conv4 + conv5 run as one kernel whenever a4 itself is not asked for (conv45_h2_kernel: a4 goes through the same per-cell
+    maximum -> power-of-two scale -> [hi | lo] planes inside LDS that conv5_h2_kernel builds from HBM): the same arithmetic in the
+    same order, so a5 and everything downstream are bit-identical to the two-kernel path behind CS_NO_FUSE45=1."""
+    x = (oracle.synth_crops(31, 0, 70) * np.float32(scale)).astype(np.float32)
+    e = Engine.from_weights(weights)
+    a5 = e.layer_output(x, 4)
+    a4 = e.layer_output(x, 3)                 # last = 3: the stand-alone conv4
+    rec = e.reconstruct(x)
+    e.close()
+    monkeypatch.setenv("CS_NO_FUSE45", "1")
+    e2 = Engine.from_weights(weights)
+    try:
+        assert np.array_equal(e2.layer_output(x, 3), a4)
+        assert np.array_equal(e2.layer_output(x, 4), a5)
+        rec2 = e2.reconstruct(x)
+        for got, want in zip(rec, rec2):
+            assert np.array_equal(got, want)
+    finally:
+        e2.close()
+
+
 def test_small_calls_run_the_detector_tail_split_with_identical_results(weights, det, monkeypatch):
     """A call of at most 16,384 cells runs the PCA GEMM's feature ranges and the SVMs' support-vector ranges side by side in separate
     workgroups (a 128-cell call is otherwise two workgroups / one workgroup walking everything in sequence) and adds the range sums in
