@@ -29,7 +29,7 @@ KERNELS = [("conv12_fused_kernel", "conv1_conv2_fused"), ("ConvCfg<64, 64, 1, 32
            ("ConvCfg<16, 16, 64, 32, 1", "conv3_relu_bn_pool"), ("ConvCfg<8, 8, 32, 32, 0", "conv4_relu_bn"),
            ("ConvCfg<16, 16, 32, 64, 0", "conv5_up_relu_bn"), ("ConvCfg<32, 32, 64, 32, 0", "conv6_up_relu_bn"),
            ("WUCfg<8, 8, 32, 64>", "conv5_up_relu_bn"), ("WUCfg<16, 16, 64, 32>", "conv6_up_relu_bn"), ("conv67_fused_kernel", "conv6_conv7_fused_err"), ("conv67_x3_kernel", "conv6_conv7_fused_err"),
-           ("conv67_h2_kernel", "conv6_conv7_fused_err"), ("conv3_wino_h2_kernel", "conv3_relu_bn_pool"), ("conv4_h2_kernel", "conv4_relu_bn"), ("conv5_h2_kernel", "conv5_up_relu_bn"),
+           ("conv67_h2_kernel", "conv6_conv7_fused_err"), ("conv45_h2_kernel", "conv5_up_relu_bn"), ("conv3_wino_h2_kernel", "conv3_relu_bn_pool"), ("conv4_h2_kernel", "conv4_relu_bn"), ("conv5_h2_kernel", "conv5_up_relu_bn"),
            ("conv3_wino_x3_kernel", "conv3_relu_bn_pool"), ("conv4_bf16x3_kernel", "conv4_relu_bn"), ("conv5_bf16x3_kernel", "conv5_up_relu_bn"), ("conv7_err_kernel", "conv7_up_sigmoid_err"), ("scaler_pca_kernel", "scaler_pca"), ("scaler_pca_x3_kernel", "scaler_pca"), ("ocsvm_mfma_kernel", "ocsvm_decision"),
            ("preprocess_kernel", "preprocess")]
 
