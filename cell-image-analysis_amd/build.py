@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcellscreen.so")
 BUILD = os.path.join(HERE, "build")
 SOURCES = ["api.hip", "conv_mfma.hip", "conv_out.hip", "detector.hip", "train.hip", "train_api.hip", "train_generic.hip", "preprocess.hip",
-           "conv_wino_cs.hip", "conv12_fused.hip", "conv45_bf16x3.hip", "conv_generic.hip", "conv_generic_x3.hip", "conv_wino_up.hip", "fit.hip"]
+           "conv_wino_cs.hip", "conv12_fused.hip", "conv45_h2.hip", "conv_generic.hip", "conv_generic_x3.hip", "conv_wino_up.hip", "fit.hip"]
 HEADERS = ["common.hpp", "api_internal.hpp", "train_internal.hpp", "tensor_archive.hpp", os.path.join("..", "..", "include", "cellscreen.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

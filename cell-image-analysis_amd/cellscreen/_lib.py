@@ -55,12 +55,34 @@ class CSTrainCfg(C.Structure):
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
 
 
+# cs_precision / CS_DEBUG_* of include/cellscreen.h
+PRECISION_SPLIT16, PRECISION_FP32_EXACT = 0, 1
+PRECISIONS = {"split16": PRECISION_SPLIT16, "fp32_exact": PRECISION_FP32_EXACT, "exact": PRECISION_FP32_EXACT,
+              PRECISION_SPLIT16: PRECISION_SPLIT16, PRECISION_FP32_EXACT: PRECISION_FP32_EXACT}
+DEBUG_NO_FUSE12, DEBUG_NO_FUSE45, DEBUG_NO_FUSE67, DEBUG_NO_SMALL_SPLIT = 1, 2, 4, 8
+
+
+class CSModelOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("debug_flags", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+
+def model_options(precision="split16", debug_flags: int = 0) -> "CSModelOptions":
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be 'split16' or 'fp32_exact', got {precision!r}")
+    o = CSModelOptions()
+    o.struct_size = C.sizeof(CSModelOptions)
+    o.precision = PRECISIONS[precision]
+    o.debug_flags = int(debug_flags)
+    return o
+
+
 class CSModelInfo(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
                 ("feature_dim", C.c_int32), ("n_components", C.c_int32),
                 ("n_sv_conservative", C.c_int32), ("n_sv_moderate", C.c_int32),
                 ("shared_encoder", C.c_int32), ("has_detector", C.c_int32), ("device_id", C.c_int32),
-                ("chunk_cells", C.c_int64), ("channels", C.c_int32 * CS_MAX_CONV), ("reference_arch", C.c_int32)]
+                ("chunk_cells", C.c_int64), ("channels", C.c_int32 * CS_MAX_CONV), ("reference_arch", C.c_int32),
+                ("precision", C.c_int32), ("debug_flags", C.c_uint32)]
 
 
 # every exported symbol of include/cellscreen.h: (restype, argtypes)
@@ -70,8 +92,9 @@ SIGNATURES = {
     "cs_status_string": (C.c_char_p, [_I]),
     "cs_last_error": (C.c_char_p, []),
     "cs_device_count": (_I, []),
-    "cs_model_load": (_I, [C.c_char_p, _I, C.POINTER(_P)]),
-    "cs_model_from_arrays": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSCaeWeights), C.POINTER(CSDetectorParams), _I, C.POINTER(_P)]),
+    "cs_model_load": (_I, [C.c_char_p, _I, C.POINTER(CSModelOptions), C.POINTER(_P)]),
+    "cs_model_from_arrays": (_I, [C.POINTER(CSCaeWeights), C.POINTER(CSCaeWeights), C.POINTER(CSDetectorParams), _I,
+                                  C.POINTER(CSModelOptions), C.POINTER(_P)]),
     "cs_model_free": (None, [_P]),
     "cs_model_wait_stream": (_I, [_P, _P]),
     "cs_model_get_info": (_I, [_P, C.POINTER(CSModelInfo)]),
@@ -147,7 +170,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.cs_abi_version() != 1:
+    if lib.cs_abi_version() != 2:
         raise RuntimeError("libcellscreen ABI version mismatch")
     _lib = lib
     return lib

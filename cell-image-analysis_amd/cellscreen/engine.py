@@ -64,30 +64,37 @@ class Engine:
         info = L.CSModelInfo()
         L.check(self._lib.cs_model_get_info(self._h, C.byref(info)))
         self.info = info
+        self.precision = "fp32_exact" if info.precision == L.PRECISION_FP32_EXACT else "split16"
 
     # ---- construction -------------------------------------------------------------
     @classmethod
     def from_weights(cls, autoencoder: CAEWeights, encoder: Optional[CAEWeights] = None,
-                     detector: Optional[DetectorParams] = None, device_id: int = 0) -> "Engine":
+                     detector: Optional[DetectorParams] = None, device_id: int = 0, precision="split16",
+                     debug_flags: int = 0) -> "Engine":
+        """precision: "split16" (default: fp32 contractions as two-term fp16 splits on the 16-bit matrix instructions, inside
+        every fp32 tolerance) or "fp32_exact" (every contraction on the fp32 matrix instructions: the reference's own
+        arithmetic, improved_detection.py:122,125,130).  debug_flags: L.DEBUG_* (unfused forms, for A/B runs and tests)."""
         lib = L.load_library()
+        opts = L.model_options(precision, debug_flags)
         keep: list = []
         ae = _fill_cae(autoencoder, keep)
         en = _fill_cae(encoder, keep) if encoder is not None else None
         de = _fill_det(detector, keep) if detector is not None else None
         h = C.c_void_p()
         L.check(lib.cs_model_from_arrays(C.byref(ae), C.byref(en) if en is not None else None,
-                                         C.byref(de) if de is not None else None, device_id, C.byref(h)))
+                                         C.byref(de) if de is not None else None, device_id, C.byref(opts), C.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_model_dir(cls, model_dir: str, device_id: int = 0) -> "Engine":
+    def from_model_dir(cls, model_dir: str, device_id: int = 0, precision="split16", debug_flags: int = 0) -> "Engine":
         """model_dir: the native file set, or the reference's six files (improved_detection.py:28-41: two `.keras`
-        archives + four pickles), which are converted on the spot."""
+        archives + four pickles), which are converted on the spot.  precision: see from_weights."""
         from . import model_io
         model_dir = model_io.ensure_native_model_dir(model_dir)
         lib = L.load_library()
         h = C.c_void_p()
-        L.check(lib.cs_model_load(model_dir.encode(), device_id, C.byref(h)))
+        opts = L.model_options(precision, debug_flags)
+        L.check(lib.cs_model_load(model_dir.encode(), device_id, C.byref(opts), C.byref(h)))
         return cls(h)
 
     def close(self):

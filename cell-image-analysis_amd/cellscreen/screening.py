@@ -20,9 +20,13 @@ from .engine import Engine
 class ProductionMutantScreening:
     def __init__(self, model_dir: str, device_id: int = 0,
                  cell_extractor: Optional[Callable[[str], Tuple[list, list]]] = None,
-                 file_pattern: str = "*.tif"):
+                 file_pattern: str = "*.tif", precision: str = "split16"):
+        """precision: "split16" (default) or "fp32_exact" -- how the fp32 contractions run (Engine.from_weights; the reference
+        predicts in Keras's float32, improved_detection.py:122,125,130: "fp32_exact" is that arithmetic up to summation order,
+        "split16" the same results inside every stated fp32 tolerance at 1.7x the rate)."""
         self.model_dir = model_dir                     # improved_detection.py:20
         self.device_id = device_id
+        self.precision = precision
         self.cell_extractor = cell_extractor
         self.file_pattern = file_pattern
         self.load_trained_models()                     # :21
@@ -31,7 +35,7 @@ class ProductionMutantScreening:
         """:23-46.  Reads the native file set (cae.bin, detector.bin); any failure raises, as
         the reference's uncaught load errors do."""
         print("Loading trained models...")
-        self.engine = Engine.from_model_dir(self.model_dir, self.device_id)
+        self.engine = Engine.from_model_dir(self.model_dir, self.device_id, precision=self.precision)
         if not self.engine.info.has_detector:
             raise FileNotFoundError(f"{self.model_dir}: detector.bin missing (scaler/pca/detector_* of :32-41)")
         print("All models loaded successfully!")

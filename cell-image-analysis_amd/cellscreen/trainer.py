@@ -76,6 +76,7 @@ class Trainer:
         self._h = h
         self._device_id = device_id
         self._sync = None
+        self._sync_error = None           # the exception a sync-BN all-gather hook raised (it cannot unwind through the C frames)
         self.bn_eps = init.bn_eps
         # the architecture: the reference graph, or any other instance of its layer grammar (csrc/train_generic.hip)
         self.channels, self.input_hw, self.n_enc = tuple(init.channels), tuple(init.input_hw), init.n_enc
@@ -137,7 +138,14 @@ class Trainer:
         yb, yp, kind2, n2 = self._buf(y)
         assert kind == kind2 and n == n2
         loss, mae = C.c_float(), C.c_float()
-        L.check(self._lib.cs_train_forward_backward(self._h, xp, yp, n, kind, C.byref(loss), C.byref(mae)))
+        try:
+            L.check(self._lib.cs_train_forward_backward(self._h, xp, yp, n, kind, C.byref(loss), C.byref(mae)))
+        except L.CellScreenError as e:
+            # a failed all-gather hook leaves the peers blocked in their collective: the caller must abort the process group
+            if self._sync_error is not None:
+                cause, self._sync_error = self._sync_error, None
+                raise e from cause
+            raise
         return loss.value, mae.value
 
     def augment(self, x, transforms):

@@ -60,7 +60,8 @@ class History:
 class ImprovedAnomalyDetectionTraining:
     def __init__(self, output_dir: str, device_id: int = 0, seed: int = 42, epochs: int = spec.EPOCHS,
                  batch_size: int = spec.BATCH_SIZE, augment="reference", verbose: int = 1,
-                 detector_fit: str = "device", data_parallel: bool = False, keras_version: int = 3, sync_bn: bool = True):
+                 detector_fit: str = "device", data_parallel: bool = False, keras_version: int = 3, sync_bn: bool = True,
+                 precision: str = "split16"):
         self.output_dir = output_dir                       # CAE_improved_modeltrain.py:26-27
         os.makedirs(output_dir, exist_ok=True)
         self.device_id = device_id
@@ -73,6 +74,7 @@ class ImprovedAnomalyDetectionTraining:
         self.detector_fit = detector_fit
         self.data_parallel = bool(data_parallel)
         self.sync_bn = bool(sync_bn)
+        self.precision = precision                         # of the screening engines this class creates (Engine.from_weights)
         self.keras_version = int(keras_version)            # EarlyStopping's restore rule differs (callbacks.py)
         self._autoencoder: Optional[CAEWeights] = None     # what the reference keeps in the Keras objects it returns
         self._best_autoencoder: Optional[CAEWeights] = None
@@ -126,7 +128,12 @@ class ImprovedAnomalyDetectionTraining:
             grad = torch.zeros(tr.n_trainable, dtype=torch.float32, device=dev)
             tr.use_grad_tensor(grad)
             if self.sync_bn:
-                tr.enable_sync_bn(dist, rank, world)
+                if tuple(X.shape[1:3]) == tuple(spec.INPUT_HW) and tuple(ae0.channels) == tuple(spec.CHANNELS):
+                    tr.enable_sync_bn(dist, rank, world)
+                else:       # cs_train_set_sync_bn serves the reference graph only (CS_ERR_UNSUPPORTED for run-time shapes)
+                    import warnings
+                    warnings.warn(f"sync_bn is available for the reference 64x64 graph only; training {tuple(X.shape[1:3])} / {tuple(ae0.channels)} "
+                                  f"with per-rank BatchNormalization statistics (pass sync_bn=False to silence this)")
         augment = self.augment
         if augment == "reference":                                                  # datagen of :246-254
             from .augment import reference_augment
@@ -216,7 +223,7 @@ class ImprovedAnomalyDetectionTraining:
     def evaluate_reconstruction_quality(self, autoencoder: CAEWeights, cell_images):
         """:328-343 numerics (plots at :345-371 are out of scope) -> (mse_errors, mae_errors)."""
         print("=== Evaluating Reconstruction Quality ===")
-        e = Engine.from_weights(autoencoder, device_id=self.device_id)
+        e = Engine.from_weights(autoencoder, device_id=self.device_id, precision=self.precision)
         _, mse, mae = e.reconstruct(np.asarray(cell_images, dtype=np.float32), want_recon=False)
         e.close()
         print(f"MSE - Mean: {np.mean(mse):.6f}, Std: {np.std(mse):.6f}")
@@ -262,7 +269,7 @@ class ImprovedAnomalyDetectionTraining:
                 print("Warning: no autoencoder given, trained or found in output_dir: the model_dir written here scores with the "
                       "detector only (its reconstruction errors come from a zero decoder)")
                 full = self._padded_autoencoder(enc_only)
-        e = Engine.from_weights(full, enc_only, device_id=self.device_id)
+        e = Engine.from_weights(full, enc_only, device_id=self.device_id, precision=self.precision)
         crops = np.ascontiguousarray(cell_images, dtype=np.float32)
         if crops.ndim == 4:
             crops = crops[..., 0]

@@ -32,8 +32,7 @@ static const char* kKernelNames[K_COUNT] = {"conv1_relu_bn_pool", "conv2_relu_bn
 
 struct ConvSet {           // one weight set on device, packed for the kernels
     DevBuf winocs[3];      // conv2 / conv3 as Winograd F(2x2,3x3): transformed-kernel fragments (index = layer)
-    DevBuf c12w1, c12w1x3; // conv1's fragments for the fused kernel (negated for filters with a negative BN scale); x3: its bf16 form
-    DevBuf c3x3, c4x3, c5x3, c6x3;   // conv3's Winograd U / conv4's / conv5's / conv6's weights as three bf16 planes
+    DevBuf c12w1;          // conv1's fragments for the fused kernel (negated for filters with a negative BN scale)
     DevBuf c3h2, c4h2, c5h2, c6h2;   // conv3's Winograd U / conv4's / conv5's / conv6's (folded) weights as two fp16 planes (the *_h2 kernels) ...
     float c3h2_inv = 1.0f, c4h2_inv = 1.0f, c5h2_inv = 1.0f, c6h2_inv = 1.0f;   // ... and 1 / their power-of-two scales
     DevBuf c12w1h2;        // conv1's weights for the fp16 form of the fused kernel's P1, and 1 / their scale
@@ -81,27 +80,14 @@ struct cs_model {
     ConvSet ae, enc;
     GenSet gae, genc;
     bool shared_encoder = true;
-    bool wino3 = getenv("CS_NO_WINO3") == nullptr;         // A/B knob: conv3 direct, conv2 Winograd
-    bool wino6 = getenv("CS_NO_WINO6") == nullptr;         // A/B knob: conv5/conv6 folded-direct instead of F(2x2,2x2) phases
-    bool wino5 = getenv("CS_NO_WINO5") == nullptr;         // A/B knob: conv5 only
-    bool fuse12 = getenv("CS_NO_FUSE12") == nullptr;       // A/B knob: conv1 and conv2 (F(2x2,3x3)) as two kernels with p1 through HBM
-    bool bf16x3 = getenv("CS_NO_BF16X3") == nullptr;       // A/B knob: conv4 on the fp32 matrix instructions instead of the split-bf16 contraction
-    bool x3conv5 = getenv("CS_NO_BF16X3_CONV5") == nullptr; // A/B knob: conv5 alone back on its Winograd fp32 kernel
-    bool x3conv3 = getenv("CS_NO_BF16X3_CONV3") == nullptr; // A/B knob: conv3's Winograd contraction on the fp32 matrix instructions
-    bool x3conv1 = getenv("CS_NO_BF16X3_CONV1") == nullptr; // A/B knob: conv1 inside the fused conv1 + conv2 kernel on the fp32 matrix instructions
-    bool x3pca = getenv("CS_NO_BF16X3_PCA") == nullptr;     // A/B knob: the PCA GEMM on the fp32 matrix instructions
-    bool fuse45 = getenv("CS_NO_FUSE45") == nullptr;         // A/B knob: conv4 and conv5 as two kernels (a4 through HBM)
-    bool small_split = getenv("CS_NO_SMALL_SPLIT") == nullptr; // A/B knob: small calls (<= DET_SPLIT_MAX_CELLS) run the detector tail's ranges side by side
-    bool x3conv6 = getenv("CS_NO_BF16X3_CONV6") == nullptr; // A/B knob: the fused conv6 + conv7 kernel with conv6 as Winograd on fp32 MFMAs
-    bool fp16x2 = getenv("CS_NO_FP16X2") == nullptr;       // A/B knob: the two-term fp16 split (3 products) back to the three-term bf16 split (6)
-    bool h2conv6 = getenv("CS_NO_FP16X2_CONV6") == nullptr; // A/B knob: conv6 (in the fused conv6 + conv7 kernel) alone
-    bool h2conv1 = getenv("CS_NO_FP16X2_CONV1") == nullptr; // conv1 inside the fused conv1 + conv2 kernel alone (needs conv2's)
-    bool h2conv3 = getenv("CS_NO_FP16X2_CONV3") == nullptr; // conv3's Winograd contraction alone
-    bool h2conv2 = getenv("CS_NO_FP16X2_CONV2") == nullptr; // conv2 inside the fused conv1 + conv2 kernel alone
-    bool h2conv4 = getenv("CS_NO_FP16X2_CONV4") == nullptr, h2conv5 = getenv("CS_NO_FP16X2_CONV5") == nullptr;   // conv4 / conv5 alone
-    bool fuse67 = getenv("CS_NO_FUSE67") == nullptr;       // A/B knob: conv6 and conv7 as two kernels even when nothing needs a6
+    // How the fp32 contractions run (cs_model_options.precision): split16 = two-term fp16 split on the 16-bit matrix instructions
+    // (PCA: three-term bf16), otherwise everything on v_mfma_f32_16x16x4_f32.  The fuse* / small_split switches are
+    // cs_model_options.debug_flags: unfused forms of the same arithmetic for A/B runs and the bit-identity tests.
+    int precision = CS_PRECISION_SPLIT16;
+    unsigned debug_flags = 0;
+    bool split16 = true;
+    bool fuse12 = true, fuse45 = true, fuse67 = true, small_split = true;
     int errparts = 4;                                      // error partial sums per cell left by the last run_convs
-    bool use_wino = getenv("CS_NO_WINOGRAD") == nullptr;   // conv2 via Winograd F(2x2,3x3); the env knob keeps the direct kernel for A/B timing
     DevBuf w7eff, b7;      // conv7: effective weights [16][32] and bias, on device
     // detector
     bool has_det = false;
@@ -268,20 +254,12 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             if (rc) return rc;
         }
         if (l == 2) {
-            std::vector<uint16_t> planes(pack_wino3_x3(nullptr, nullptr));
-            pack_wino3_x3(w->kernel[l], planes.data());
-            rc = upload(set.c3x3, planes.data(), planes.size() * sizeof(uint16_t));
-            if (rc) return rc;
             std::vector<uint16_t> h2(pack_wino3_h2(nullptr, nullptr, nullptr));
             pack_wino3_h2(w->kernel[l], h2.data(), &set.c3h2_inv);
             rc = upload(set.c3h2, h2.data(), h2.size() * sizeof(uint16_t));
             if (rc) return rc;
         }
         if (l == 3) {
-            std::vector<uint16_t> planes(pack_conv4_bf16x3(nullptr, nullptr));
-            pack_conv4_bf16x3(w->kernel[l], planes.data());
-            rc = upload(set.c4x3, planes.data(), planes.size() * sizeof(uint16_t));
-            if (rc) return rc;
             std::vector<uint16_t> h2(pack_conv4_f16x2(nullptr, nullptr, nullptr));
             pack_conv4_f16x2(w->kernel[l], h2.data(), &set.c4h2_inv);
             rc = upload(set.c4h2, h2.data(), h2.size() * sizeof(uint16_t));
@@ -290,10 +268,6 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
         if (l == 4) {
             std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
             pack_generic_folded(cin, cout, w->kernel[l], weff.data());
-            std::vector<uint16_t> planes(pack_conv5_bf16x3(nullptr, nullptr));
-            pack_conv5_bf16x3(weff.data(), planes.data());
-            rc = upload(set.c5x3, planes.data(), planes.size() * sizeof(uint16_t));
-            if (rc) return rc;
             std::vector<uint16_t> h2(pack_conv5_f16x2(nullptr, nullptr, nullptr));
             pack_conv5_f16x2(weff.data(), h2.data(), &set.c5h2_inv);
             rc = upload(set.c5h2, h2.data(), h2.size() * sizeof(uint16_t));
@@ -302,10 +276,6 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
         if (l == 5) {
             std::vector<float> weff(pack_generic_folded(cin, cout, nullptr, nullptr));
             pack_generic_folded(cin, cout, w->kernel[l], weff.data());
-            std::vector<uint16_t> planes(pack_conv6_bf16x3(nullptr, nullptr));
-            pack_conv6_bf16x3(weff.data(), planes.data());
-            rc = upload(set.c6x3, planes.data(), planes.size() * sizeof(uint16_t));
-            if (rc) return rc;
             std::vector<uint16_t> h2(pack_conv6_f16x2(nullptr, nullptr, nullptr));
             pack_conv6_f16x2(weff.data(), h2.data(), &set.c6h2_inv);
             rc = upload(set.c6h2, h2.data(), h2.size() * sizeof(uint16_t));
@@ -315,10 +285,6 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
             tmp.resize(pack_conv12_conv1_fragments(nullptr, nullptr, nullptr));
             pack_conv12_conv1_fragments(w->kernel[l], ep.data() + cout, tmp.data());
             rc = upload(set.c12w1, tmp.data(), tmp.size() * sizeof(float));
-            if (rc) return rc;
-            std::vector<unsigned int> wx(pack_conv12_conv1_x3(nullptr, nullptr, nullptr));
-            pack_conv12_conv1_x3(w->kernel[l], ep.data() + cout, wx.data());
-            rc = upload(set.c12w1x3, wx.data(), wx.size() * sizeof(unsigned int));
             if (rc) return rc;
             pack_conv12_p1_bound(w->kernel[l], ep.data(), &set.p1a, &set.p1b);
             std::vector<unsigned int> wh(pack_conv12_conv1_h2(nullptr, nullptr, nullptr, nullptr));
@@ -342,7 +308,7 @@ static int pack_set(ConvSet& set, const cs_cae_weights* w, int count)
 }
 
 // Generic architectures: HWIO kernels as they are + the [3][cout] epilogue (bias only for the sigmoid conv).
-static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int count)
+static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int count, bool split16)
 {
     for (int l = 0; l < count; ++l) {
         const int cin = a.cin(l), cout = a.ch[l];
@@ -355,13 +321,13 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
             std::vector<float> wf(pack_generic_folded(cin, cout, nullptr, nullptr));
             pack_generic_folded(cin, cout, w->kernel[l], wf.data());
             if ((rc = upload(set.wf[l], wf.data(), wf.size() * sizeof(float)))) return rc;
-            if (l == a.n_conv - 1 && cout == 1 && conv_last_x3_takes(a.gh[l], a.gw[l], cin)) {
+            if (split16 && l == a.n_conv - 1 && cout == 1 && conv_last_x3_takes(a.gh[l], a.gw[l], cin)) {
                 std::vector<uint16_t> pl(pack_last_bf16x3(cin, nullptr, nullptr));
                 pack_last_bf16x3(cin, wf.data(), pl.data());
                 if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
                 set.x3[l] = true;
             }
-            if (l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 1)) {
+            if (split16 && l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 1)) {
                 std::vector<uint16_t> pl(pack_generic_bf16x3(16, cin, cout, nullptr, nullptr));
                 pack_generic_bf16x3(16, cin, cout, wf.data(), pl.data());
                 if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
@@ -370,7 +336,7 @@ static int pack_generic(GenSet& set, const cs_cae_weights* w, const Arch& a, int
                 pack_generic_f16x2(16, cin, cout, wf.data(), ph.data(), &set.h2_inv[l]);
                 if ((rc = upload(set.wh2[l], ph.data(), ph.size() * sizeof(uint16_t)))) return rc;
             }
-        } else if (l <= a.n_enc && l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 0)) {
+        } else if (split16 && l <= a.n_enc && l < a.n_conv - 1 && conv_generic_x3_takes(a.gh[l], a.gw[l], cin, cout, 0)) {
             std::vector<uint16_t> pl(pack_generic_bf16x3(9, cin, cout, nullptr, nullptr));
             pack_generic_bf16x3(9, cin, cout, w->kernel[l], pl.data());
             if ((rc = upload(set.wx3[l], pl.data(), pl.size() * sizeof(uint16_t)))) return rc;
@@ -458,7 +424,7 @@ static int ensure_workspace(cs_model* m, int64_t cells, bool need_recon)
         int rc;
         if ((rc = m->xin.ensure((size_t)cells * m->arch.npix * sizeof(float)))) return rc;
         // p1 (131 KB per cell, the largest activation) is not materialised when conv1 + conv2 run fused: allocated on demand
-        const bool skip_p1 = m->arch.ref && m->fuse12 && m->use_wino;
+        const bool skip_p1 = m->arch.ref && m->fuse12;
         for (int l = skip_p1 ? 1 : 0; l < m->arch.n_conv - 1; ++l)
             if ((rc = m->act[l].ensure((size_t)cells * m->arch.floats[l] * sizeof(float)))) return rc;
         if ((rc = m->featE.ensure((size_t)cells * m->arch.feat() * sizeof(float)))) return rc;
@@ -534,14 +500,14 @@ static int run_convs_generic(cs_model* m, const GenSet& set, const float* x, int
         float* out = is_last ? (recon ? recon : m->recon.as<float>()) : m->act[l].as<float>();
         const int epi = is_last ? GEN_EPI_SIGMOID : (l < a.n_enc ? GEN_EPI_BN_POOL : GEN_EPI_BN);
         const int kid = l < 6 ? K_CONV1 + l : K_CONV7_ERR;       // profile bucket: by position
-        if (set.x3[l] && m->bf16x3 && is_last) {
+        if (set.x3[l] && m->split16 && is_last) {
             LAUNCH(kid, nc,
                    launch_conv_last_x3(in, set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc, a.gh[l], a.gw[l], a.cin(l), m->stream));
             LAUNCH(K_CONV7_ERR, nc, launch_recon_err(out, x, nc, (int)a.npix, m->errpart.as<float>(), m->stream));
             continue;
         }
-        if (set.x3[l] && m->bf16x3) {
-            const bool h2 = m->fp16x2 && set.h2_inv[l] != 0.0f;
+        if (set.x3[l] && m->split16) {
+            const bool h2 = set.h2_inv[l] != 0.0f;
             LAUNCH(kid, nc,
                    launch_conv_generic_x3(in, h2 ? set.wh2[l].as<uint16_t>() : set.wx3[l].as<uint16_t>(), set.ep[l].as<float>(), out, nc,
                                           a.gh[l], a.gw[l], a.cin(l), a.ch[l], l > a.n_enc, epi, m->stream, h2 ? set.h2_inv[l] : 0.0f));
@@ -562,23 +528,22 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
 {
     if (!m->arch.ref) return run_convs_generic(m, &set == &m->enc ? m->genc : m->gae, x, nc, first, last, recon);
     // screening needs neither a6 nor the reconstruction: conv6, conv7 and the error sums run as one kernel
-    const bool fused = m->fuse67 && m->use_wino && m->wino6 && first <= 5 && last >= 6 && !recon;
+    const bool fused = m->fuse67 && first <= 5 && last >= 6 && !recon;
     // conv1 + conv2 as one kernel whenever p1 itself is not asked for (it is never written then)
-    const bool fused12 = m->fuse12 && m->use_wino && first == 0 && last >= 1;
+    const bool fused12 = m->fuse12 && first == 0 && last >= 1;
+    const bool h2 = m->split16;
     if (fused12) {
-        const bool c1x3 = m->bf16x3 && m->x3conv1, c2h = c1x3 && m->fp16x2 && m->h2conv2, c1h = c2h && m->h2conv1;
         LAUNCH(K_CONV12_FUSED, nc,
                launch_conv12_fused(x, set.c12w1.as<float>(), set.ep[0].as<float>(), set.c12.as<float>(), set.ep[1].as<float>(),
-                                   m->act[1].as<float>(), nc, m->stream, c1x3 ? set.c12w1x3.as<unsigned int>() : nullptr,
-                                   c2h ? set.c12h2.as<unsigned int>() : nullptr, set.p1a, set.p1b, set.c12h2_inv,
-                                   c1h ? set.c12w1h2.as<unsigned int>() : nullptr, set.c12w1h2_inv));
+                                   m->act[1].as<float>(), nc, m->stream, h2 ? set.c12h2.as<unsigned int>() : nullptr, set.p1a, set.p1b,
+                                   set.c12h2_inv, h2 ? set.c12w1h2.as<unsigned int>() : nullptr, set.c12w1h2_inv));
     }
-    if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / A-B knob) needs p1 in HBM
+    if (!fused12 && first == 0) {   // the stand-alone conv1 (stage tap / debug flag) needs p1 in HBM
         int rc = m->act[0].ensure((size_t)m->ws_cells * m->arch.floats[0] * sizeof(float));
         if (rc) return rc;
     }
     // conv4 + conv5 as one kernel when a4 itself is not asked for (conv5 is bound by its HBM writes: conv4 rides under them)
-    const bool fused45 = m->fuse45 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv4 && m->h2conv5 && first <= 3 && last >= 4;
+    const bool fused45 = m->fuse45 && h2 && first <= 3 && last >= 4;
     for (int l = fused12 ? 2 : first; l <= last && l < (fused ? 5 : 6); ++l) {
         const float* in = l == 0 ? x : m->act[l - 1].as<float>();
         if (l == 3 && fused45) {
@@ -588,57 +553,37 @@ static int run_convs(cs_model* m, const ConvSet& set, const float* x, int64_t nc
             ++l;            // conv5 is done too
             continue;
         }
-        if (l == 4 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv5) {
+        if (l == 4 && h2) {
             LAUNCH(K_CONV5, nc,
                    launch_conv5_h2(in, set.c5h2.as<uint16_t>(), set.c5h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
-        if (l == 4 && m->bf16x3 && m->x3conv5) {
-            LAUNCH(K_CONV5, nc,
-                   launch_conv5_bf16x3(in, set.c5x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
-            continue;
-        }
-        if ((l == 5 || (l == 4 && m->wino5)) && m->use_wino && m->wino6) {
+        if (l == 4 || l == 5) {     // fp32: four Winograd F(2x2,2x2) phase convs over the stored grid
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_up(l, in, set.winoup[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
-        if (l == 2 && m->wino3 && m->use_wino && m->bf16x3 && m->x3conv3 && m->fp16x2 && m->h2conv3) {
+        if (l == 2 && h2) {
             LAUNCH(K_CONV3, nc,
                    launch_conv3_wino_h2(in, set.c3h2.as<uint16_t>(), set.c3h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
-        if (l == 2 && m->wino3 && m->use_wino && m->bf16x3 && m->x3conv3) {
-            LAUNCH(K_CONV3, nc,
-                   launch_conv3_wino_x3(in, set.c3x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
-            continue;
-        }
-        if ((l == 1 || (l == 2 && m->wino3)) && m->use_wino) {
+        if (l == 1 || l == 2) {     // fp32 Winograd F(2x2,3x3)
             LAUNCH(K_CONV1 + l, nc,
                    launch_conv_wino_cs(l, in, set.winocs[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
-        if (l == 3 && m->bf16x3 && m->fp16x2 && m->h2conv4) {
+        if (l == 3 && h2) {
             LAUNCH(K_CONV4, nc,
                    launch_conv4_h2(in, set.c4h2.as<uint16_t>(), set.c4h2_inv, set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
             continue;
         }
-        if (l == 3 && m->bf16x3) {
-            LAUNCH(K_CONV4, nc,
-                   launch_conv4_bf16x3(in, set.c4x3.as<uint16_t>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream));
-            continue;
-        }
-        LAUNCH(K_CONV1 + l, nc,
-               launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, l == 4 || l == 5));
+        LAUNCH(K_CONV1 + l, nc,      // conv1 alone; conv4 in fp32
+               launch_conv_mfma(l, in, set.wfrag[l].as<float>(), set.ep[l].as<float>(), m->act[l].as<float>(), nc, m->stream, false));
     }
-    if (fused && m->bf16x3 && m->x3conv6 && m->fp16x2 && m->h2conv6) {
+    if (fused && h2) {
         LAUNCH(K_CONV67_FUSED, nc,
                launch_conv67_h2(m->act[4].as<float>(), set.c6h2.as<uint16_t>(), set.c6h2_inv, set.ep[5].as<float>(), x, m->w7eff.as<float>(),
-                                m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
-        m->errparts = conv67_fused_nparts();
-    } else if (fused && m->bf16x3 && m->x3conv6) {
-        LAUNCH(K_CONV67_FUSED, nc,
-               launch_conv67_x3(m->act[4].as<float>(), set.c6x3.as<uint16_t>(), set.ep[5].as<float>(), x, m->w7eff.as<float>(),
                                 m->b7.as<float>(), m->errpart.as<float>(), nc, m->stream));
         m->errparts = conv67_fused_nparts();
     } else if (fused) {
@@ -748,11 +693,44 @@ int cs_device_count(void)
     return n;
 }
 
+// cs_model_options -> (precision, debug flags).  The environment may override both for a debugging session without a rebuild
+// of the caller (CS_DEBUG_PRECISION=exact|split16, CS_DEBUG_FLAGS=<mask>); nothing else in the library reads the environment
+// to choose arithmetic.
+static int resolve_options(const cs_model_options* o, int* precision, unsigned* flags)
+{
+    *precision = CS_PRECISION_SPLIT16;
+    *flags = 0;
+    if (o) {
+        if (o->struct_size < 12 || o->struct_size > 4096) return fail(CS_ERR_INVALID, "cs_model_options.struct_size = %u (set it to sizeof(cs_model_options))", o->struct_size);
+        if (o->precision != CS_PRECISION_SPLIT16 && o->precision != CS_PRECISION_FP32_EXACT)
+            return fail(CS_ERR_INVALID, "cs_model_options.precision = %d (CS_PRECISION_SPLIT16 or CS_PRECISION_FP32_EXACT)", o->precision);
+        const unsigned known = CS_DEBUG_NO_FUSE12 | CS_DEBUG_NO_FUSE45 | CS_DEBUG_NO_FUSE67 | CS_DEBUG_NO_SMALL_SPLIT;
+        if (o->debug_flags & ~known) return fail(CS_ERR_INVALID, "cs_model_options.debug_flags = 0x%x has unknown bits", o->debug_flags);
+        if (o->struct_size >= sizeof(cs_model_options))
+            for (unsigned r : o->reserved) if (r) return fail(CS_ERR_INVALID, "cs_model_options.reserved must be 0");
+        *precision = o->precision;
+        *flags = o->debug_flags;
+    }
+    if (const char* e = getenv("CS_DEBUG_PRECISION")) {
+        if (!strcmp(e, "exact")) *precision = CS_PRECISION_FP32_EXACT;
+        else if (!strcmp(e, "split16")) *precision = CS_PRECISION_SPLIT16;
+        else return fail(CS_ERR_INVALID, "CS_DEBUG_PRECISION=%s (exact or split16)", e);
+    }
+    if (const char* e = getenv("CS_DEBUG_FLAGS")) *flags |= (unsigned)strtoul(e, nullptr, 0) & 0xfu;
+    return CS_OK;
+}
+
 int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights* encoder,
-                         const cs_detector_params* det, int device_id, cs_model** out)
+                         const cs_detector_params* det, int device_id, const cs_model_options* options, cs_model** out)
 {
     if (!out) return fail(CS_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    int precision;
+    unsigned dflags;
+    {
+        int rco = resolve_options(options, &precision, &dflags);
+        if (rco) return rco;
+    }
     Arch arch;
     int rc = describe_arch(autoencoder, arch);
     if (rc) return rc;
@@ -764,6 +742,13 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
     if (!m) return fail(CS_ERR_NOMEM, "host allocation failed");
     m->device = device_id;
     m->arch = arch;
+    m->precision = precision;
+    m->debug_flags = dflags;
+    m->split16 = precision == CS_PRECISION_SPLIT16;
+    m->fuse12 = !(dflags & CS_DEBUG_NO_FUSE12);
+    m->fuse45 = !(dflags & CS_DEBUG_NO_FUSE45);
+    m->fuse67 = !(dflags & CS_DEBUG_NO_FUSE67);
+    m->small_split = !(dflags & CS_DEBUG_NO_SMALL_SPLIT);
 #define FAIL_IF(x) do { int r__ = (x); if (r__) { delete m; return r__; } } while (0)
     {
         hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
@@ -781,12 +766,12 @@ int cs_model_from_arrays(const cs_cae_weights* autoencoder, const cs_cae_weights
         FAIL_IF(upload(m->w7eff, weff, sizeof weff));
         FAIL_IF(upload(m->b7, autoencoder->bias[6], sizeof(float)));
     } else {
-        FAIL_IF(pack_generic(m->gae, autoencoder, arch, arch.n_conv));
+        FAIL_IF(pack_generic(m->gae, autoencoder, arch, arch.n_conv, m->split16));
     }
     m->shared_encoder = !encoder || same_encoder(autoencoder, encoder, arch);
     if (!m->shared_encoder) {
         if (arch.ref) FAIL_IF(pack_set(m->enc, encoder, kNEnc));
-        else FAIL_IF(pack_generic(m->genc, encoder, arch, arch.n_enc));
+        else FAIL_IF(pack_generic(m->genc, encoder, arch, arch.n_enc, m->split16));
     }
 
     if (det) {
@@ -864,7 +849,7 @@ static int fill_svm(const TensorArchive& ar, const std::string& prefix, int C, c
     return CS_OK;
 }
 
-int cs_model_load(const char* model_dir, int device_id, cs_model** out)
+int cs_model_load(const char* model_dir, int device_id, const cs_model_options* options, cs_model** out)
 {
     if (!out) return fail(CS_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -921,7 +906,7 @@ int cs_model_load(const char* model_dir, int device_id, cs_model** out)
         if ((rc = fill_svm(det, "svm_moderate", dp.n_components, &dp.moderate, dir + "/detector.bin"))) return rc;
         dpp = &dp;
     }
-    return cs_model_from_arrays(&ae, enp, dpp, device_id, out);
+    return cs_model_from_arrays(&ae, enp, dpp, device_id, options, out);
 }
 
 void cs_model_free(cs_model* m)
@@ -940,6 +925,8 @@ int cs_model_get_info(const cs_model* m, cs_model_info* info)
     info->feature_dim = (int32_t)m->arch.feat();
     for (int l = 0; l < m->arch.n_conv; ++l) info->channels[l] = m->arch.ch[l];
     info->reference_arch = m->arch.ref ? 1 : 0;
+    info->precision = m->precision;
+    info->debug_flags = m->debug_flags;
     info->n_components = m->C;
     info->n_sv_conservative = m->svm[0].nsv;
     info->n_sv_moderate = m->svm[1].nsv;
@@ -961,7 +948,7 @@ int cs_model_set_chunk(cs_model* m, int64_t chunk_cells)
 static int run_tail(cs_model* m, const float* feat, int64_t nc, float* mse, float* mae, double* sc, double* sm,
                     int8_t* pc, int8_t* pm, bool with_err)
 {
-    if (m->bf16x3 && m->x3pca)
+    if (m->split16)
         LAUNCH(K_SCALER_PCA, nc,
                launch_scaler_pca_x3(feat, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
                                     m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream, m->det_ws.p));
@@ -1207,7 +1194,7 @@ int cs_scaler_pca(cs_model* m, const float* features, int64_t n, int in_kind, fl
         const int64_t nc = (n - off) < ch ? (n - off) : ch;
         const float* f;
         if ((rc = stage_in(m, features, in_kind, off, nc, (size_t)m->F, m->featE, &f))) return rc;
-        if (m->bf16x3 && m->x3pca)
+        if (m->split16)
             LAUNCH(K_SCALER_PCA, nc,
                    launch_scaler_pca_x3(f, m->center.as<float>(), m->scale.as<double>(), m->comps_x3.as<uint16_t>(),
                                         m->mean_proj.as<float>(), m->F, m->fpad, m->C, m->cpad, m->pca.as<float>(), nc, m->stream, m->det_ws.p));
@@ -1318,23 +1305,23 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
     if (!m || !mfma || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
     double v = 0.0;
     if (m->arch.ref) {
-        const bool wn = m->use_wino;
+        const bool h2 = m->split16;
         switch (k) {
             case K_CONV1: v = 1536; break;                                  // 256 tiles x 2 slices x 3 K steps
-            case K_CONV2: v = wn ? 8192 : 18432; break;                     // F(2x2,3x3): 16 points x 16 groups x 8 x 4
-            case K_CONV3: v = (wn && m->wino3) ? ((m->bf16x3 && m->x3conv3) ? 0 : 2048) : 4608; break;
-            case K_CONV4: v = m->bf16x3 ? 0 : 576; break;                   // split-bf16: 432 v_mfma_f32_16x16x32_bf16, a different instruction and peak -- not counted here
-            case K_CONV5: v = (m->bf16x3 && m->x3conv5) ? 0 : ((wn && m->wino6 && m->wino5) ? 1152 : 2048); break;   // folded upsample 4/9; F(2x2,2x2) phases 1/4
-            case K_CONV6: v = (wn && m->wino6) ? 4608 : 8192; break;
-            case K_CONV67_FUSED: v = (m->bf16x3 && m->x3conv6) ? 512 : 4608 + 512; break;   // conv6 phases (unless on bf16 MFMAs) + conv7's 32 -> 16 contraction
-            case K_CONV12_FUSED: v = (m->bf16x3 && m->x3conv1) ? ((m->fp16x2 && m->h2conv2) ? 0 : 4608) : 4608 + 1536 + 48; break;   // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct (unless on bf16 MFMAs);
+            case K_CONV2: v = 8192; break;                                  // F(2x2,3x3): 16 points x 16 groups x 8 x 4
+            case K_CONV3: v = h2 ? 0 : 2048; break;
+            case K_CONV4: v = h2 ? 0 : 576; break;                          // the split forms run on v_mfma_f32_16x16x32_f16: cs_profile_bf16_mfma_per_cell
+            case K_CONV5: v = h2 ? 0 : 1152; break;                         // F(2x2,2x2) phases: 1/4 of the direct conv's multiply-adds
+            case K_CONV6: v = 4608; break;
+            case K_CONV67_FUSED: v = h2 ? 512 : 4608 + 512; break;          // conv6 phases (unless on the 16-bit pipe) + conv7's 32 -> 16 contraction
+            case K_CONV12_FUSED: v = h2 ? 0 : 4608 + 1536 + 48; break;      // conv2 F(4x4,3x3): 36 points x 4 groups x 8 x 4; conv1 direct
                                                                             // + the discarded fourth row of a cell's last 4-row batch
-            case K_SCALER_PCA: v = (m->bf16x3 && m->x3pca) ? 0.0 : (double)m->fpad * m->cpad / 1024.0; break;
+            case K_SCALER_PCA: v = h2 ? 0.0 : (double)m->fpad * m->cpad / 1024.0; break;
             default: v = 0.0;
         }
     } else if (k <= K_CONV6 || k == K_CONV7_ERR) {
         const int l = k == K_CONV7_ERR ? m->arch.n_conv - 1 : k - K_CONV1;
-        if (l < m->arch.n_conv && !(m->bf16x3 && m->gae.x3[l])) {      // split-bf16 layers: cs_profile_bf16_mfma_per_cell
+        if (l < m->arch.n_conv && !(m->split16 && m->gae.x3[l])) {      // split-bf16 layers: cs_profile_bf16_mfma_per_cell
             const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
             v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * (9.0 * m->arch.cin(l) / 4.0);
         }
@@ -1343,34 +1330,31 @@ int cs_profile_mfma_per_cell(cs_model* m, int k, double* mfma)
     return CS_OK;
 }
 
-// The same for the kernels that take the fp32 contraction on the bf16 matrix pipe (conv45_bf16x3.hip, conv_generic_x3.hip):
-// v_mfma_f32_16x16x32_bf16 instructions (16,384 FLOP each; six per 16 pixels x 16 filters x 32 channels) per cell.
+// The same for the kernels that take the fp32 contraction on the 16-bit matrix pipe (CS_PRECISION_SPLIT16): v_mfma_f32_16x16x32_{f16,bf16}
+// instructions (16,384 FLOP each; three (fp16 split) or six (bf16 split) per 16 pixels x 16 filters x 32 channels) per cell.
 int cs_profile_bf16_mfma_per_cell(cs_model* m, int k, double* mfma)
 {
     if (!m || !mfma || k < 0 || k >= K_COUNT) return fail(CS_ERR_INVALID, "bad kernel id");
     double v = 0.0;
-    if (k == K_SCALER_PCA && m->bf16x3 && m->x3pca && m->has_det) {
-        *mfma = (double)(m->cpad / 16) * (m->fpad / 32) * 6.0 / 16.0;      // per 16-cell tile: component tiles x 32-feature blocks x 6
+    if (!m->split16) { *mfma = 0.0; return CS_OK; }
+    if (k == K_SCALER_PCA && m->has_det) {
+        *mfma = (double)(m->cpad / 16) * (m->fpad / 32) * 6.0 / 16.0;      // per 16-cell tile: component tiles x 32-feature blocks x 6 (bf16 split)
         return CS_OK;
     }
-    if (m->arch.ref) {
-        if (k == K_CONV4 && m->bf16x3) v = 4 * 2 * 9 * ((m->fp16x2 && m->h2conv4) ? 3 : 6);   // 4 tiles x 2 slices x 9 taps x 6 (bf16 split) or 3 (fp16 split) products
-        if (k == K_CONV3 && m->bf16x3 && m->x3conv3 && m->use_wino && m->wino3)      // 16 points x 4 tile groups x 2 slices x 2 blocks x 6 (bf16 split) | 3 (fp16 split)
-            v = 16.0 * 4 * 2 * 2 * ((m->fp16x2 && m->h2conv3) ? 3 : 6);
-        if (k == K_CONV12_FUSED && m->bf16x3 && m->x3conv1)               // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 3 MFMAs;
-            v = 66 * 8 * ((m->fp16x2 && m->h2conv2 && m->h2conv1) ? 2 : 3)                   // (conv1 as an fp16 split: 2 MFMAs)
-                + ((m->fp16x2 && m->h2conv2) ? 36 * 4 * 4 * 3 : 0);   // conv2 as an fp16 split: 36 points x 4 tile groups x 4 slices x 3 products
-        if (k == K_CONV5 && m->bf16x3 && m->x3conv5) v = 4 * 4 * 4 * 4 * ((m->fp16x2 && m->h2conv5) ? 3 : 6);   // 4 phases x 4 tiles x 4 slices x 4 taps x 6 | 3 products
-        if (k == K_CONV5 && m->fuse45 && m->bf16x3 && m->x3conv5 && m->fp16x2 && m->h2conv4 && m->h2conv5) v += 4 * 2 * 9 * 3;   // + conv4 inside the fused conv4 + conv5 kernel
-        if (k == K_CONV67_FUSED && m->bf16x3 && m->x3conv6)          // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks x 6 (bf16 split) or 3 (fp16 split)
-            v = 4.0 * 16 * 2 * 4 * 2 * ((m->fp16x2 && m->h2conv6) ? 3 : 6);
-    } else if (k <= K_CONV6 && m->bf16x3) {
+    if (m->arch.ref) {                                                     // fp16 split: 3 products per (16 px, 16 filters, 32 channels)
+        if (k == K_CONV4) v = 4 * 2 * 9 * 3;                               // 4 tiles x 2 slices x 9 taps
+        if (k == K_CONV3) v = 16.0 * 4 * 2 * 2 * 3;                        // 16 points x 4 tile groups x 2 slices x 2 blocks
+        if (k == K_CONV12_FUSED) v = 66 * 8 * 2 + 36 * 4 * 4 * 3;          // conv1: 66 conv rows (one pooled row discarded) x 8 (x-tile, slice) x 2 MFMAs;
+                                                                           // conv2: 36 points x 4 tile groups x 4 slices x 3
+        if (k == K_CONV5) v = 4 * 4 * 4 * 4 * 3 + (m->fuse45 ? 4 * 2 * 9 * 3 : 0);   // 4 phases x 4 tiles x 4 slices x 4 taps (+ conv4 inside the fused kernel)
+        if (k == K_CONV67_FUSED) v = 4.0 * 16 * 2 * 4 * 2 * 3;             // 4 phases x 16 tiles x 2 slices x 4 taps x 2 blocks
+    } else if (k <= K_CONV6) {
         const int l = k - K_CONV1;
         if (l < m->arch.n_conv && m->gae.x3[l]) {
             const int cout_pad = (m->arch.ch[l] + 15) / 16 * 16;
             const double taps = l > m->arch.n_enc ? 4.0 : 9.0;             // folded upsample: 16 (phase, tap) pairs over a quarter of the grid
             const bool last = l == m->arch.n_conv - 1;
-            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * taps * (m->arch.cin(l) / 32.0) * ((m->fp16x2 && m->gae.h2_inv[l] != 0.0f && !last) ? 3.0 : 6.0);
+            v = (double)m->arch.gh[l] * m->arch.gw[l] / 16.0 * (cout_pad / 16) * taps * (m->arch.cin(l) / 32.0) * ((m->gae.h2_inv[l] != 0.0f && !last) ? 3.0 : 6.0);
         }
     }
     *mfma = v;

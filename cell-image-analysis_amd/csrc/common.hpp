@@ -93,35 +93,25 @@ size_t pack_conv_fragments_folded(int cin, int cout, const float* hwio, float* d
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream);
 size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst);
-// conv3 (layer 2) in the same Winograd form with the contraction on the bf16 matrix pipe (six split products), one wave per SIMD
-hipError_t launch_conv3_wino_x3(const float* in, const uint16_t* uplanes, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
-size_t pack_wino3_x3(const float* hwio, uint16_t* dst);       // returns the number of bf16 values
-// ... and as a two-term fp16 split (three products, two workgroups per CU): planes + 1 / (their power-of-two scale)
+// conv3 (layer 2) in the same Winograd form with the contraction as a two-term fp16 split (three products, two workgroups per CU):
+// planes + 1 / (their power-of-two scale)
 hipError_t launch_conv3_wino_h2(const float* in, const uint16_t* uplanes, float inv_sw, const float* ep, float* out, int64_t n_cells,
                                 hipStream_t stream);
 size_t pack_wino3_h2(const float* hwio, uint16_t* dst, float* inv_sw);
 // conv1 + conv2 in one kernel (crop -> p2), conv2 as Winograd F(4x4,3x3): conv12_fused.hip.  w1frag comes from
 // pack_conv12_conv1_fragments, ep1 / ep2 are the layers' [3][cout] epilogue arrays, ufrag comes from pack_conv12_fragments (conv2's HWIO kernel).
-// w1x3 (optional, pack_conv12_conv1_x3): conv1 runs on bf16 MFMAs (the three bf16 planes of the crop packed along K)
-// ufrag_h2 (optional, with w1x3; pack_conv12_fragments_h2): conv2's contraction as a two-term fp16 split; p1a / p1b = pack_conv12_p1_bound,
-// inv_sw = 1 / the scale of ufrag_h2
+// CS_PRECISION_SPLIT16: ufrag_h2 (pack_conv12_fragments_h2) and w1h2 (pack_conv12_conv1_h2) both non-null -- conv2's and conv1's
+// contractions as two-term fp16 splits; p1a / p1b = pack_conv12_p1_bound, inv_sw / inv_sw1 = 1 / the scales of ufrag_h2 / w1h2.
+// Both null: everything on the fp32 matrix instructions.
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3 = nullptr, const unsigned int* ufrag_h2 = nullptr,
+                               int64_t n_cells, hipStream_t stream, const unsigned int* ufrag_h2 = nullptr,
                                float p1a = 0.0f, float p1b = 0.0f, float inv_sw = 1.0f, const unsigned int* w1h2 = nullptr, float inv_sw1 = 1.0f);
-// w1h2 (optional, with ufrag_h2; pack_conv12_conv1_h2): conv1 too as a two-term fp16 split (two MFMAs per 16 pixels x 16 filters)
 size_t pack_conv12_conv1_h2(const float* hwio, const float* bn_scale, unsigned int* dst, float* inv_sw1);     // returns 32-bit words
 size_t pack_conv12_fragments_h2(const float* hwio, const float* bn_scale, unsigned int* dst, float* inv_sw);     // returns 32-bit words
 void pack_conv12_p1_bound(const float* hwio1, const float* ep1, float* a1, float* b1);
-size_t pack_conv12_conv1_x3(const float* hwio, const float* bn_scale, unsigned int* dst);     // returns 32-bit words
 size_t pack_conv12_fragments(const float* hwio, const float* bn_scale, float* dst);
 size_t pack_conv12_conv1_fragments(const float* hwio, const float* bn_scale, float* dst);
-// conv4 (layer 3) with the fp32 contraction on the bf16 matrix pipe (three-way operand split, six products): conv45_bf16x3.hip
-hipError_t launch_conv4_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
-size_t pack_conv4_bf16x3(const float* hwio, uint16_t* dst);     // returns the number of bf16 values
-// conv5 (layer 4) likewise, on the folded-upsample form: weff = pack_generic_folded(32, 64, hwio, .)
-hipError_t launch_conv5_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
-size_t pack_conv5_bf16x3(const float* weff, uint16_t* dst);
-// conv4 / conv5 as a two-term fp16 split (three products; conv45_bf16x3.hip): planes + 1 / (their power-of-two scale)
+// conv4 / conv5 as a two-term fp16 split (three products; conv45_h2.hip): planes + 1 / (their power-of-two scale)
 hipError_t launch_conv4_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
 size_t pack_conv4_f16x2(const float* hwio, uint16_t* dst, float* inv_sw);
 hipError_t launch_conv5_h2(const float* in, const uint16_t* wfrag, float inv_sw, const float* ep, float* out, int64_t n_cells, hipStream_t stream);
@@ -144,11 +134,7 @@ size_t pack_conv_fragments(int cin, int cout, const float* hwio, float* dst);
 hipError_t launch_conv67_fused(const float* a5, const float* ufrag, const float* ep, const float* x, const float* weff_dev,
                                const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
 int conv67_fused_nparts();
-// the same kernel with conv6 (folded direct form) on the bf16 matrix pipe: wplanes = pack_conv6_bf16x3(pack_generic_folded(64, 32, hwio, .))
-hipError_t launch_conv67_x3(const float* a5, const uint16_t* wplanes, const float* ep, const float* x, const float* weff_dev,
-                            const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);
-size_t pack_conv6_bf16x3(const float* weff, uint16_t* dst);
-// ... and as a TWO-term fp16 split (three products, power-of-two operand scales; conv_wino_up.hip has the algebra):
+// the same kernel with conv6 (folded direct form) as a TWO-term fp16 split (three products, power-of-two operand scales; conv_wino_up.hip has the algebra):
 // wplanes = pack_conv6_f16x2(pack_generic_folded(64, 32, hwio, .), ., &inv_sw)
 hipError_t launch_conv67_h2(const float* a5, const uint16_t* wplanes, float inv_sw, const float* ep, const float* x, const float* weff_dev,
                             const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream);

@@ -122,23 +122,8 @@ __device__ __forceinline__ unsigned long long c12_stamp()
         dt = t__;                                                          \
     }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// x -> the bf16 record [x1, x2, x3, x1] of the split-bf16 conv1 (x = x1 + x2 + x3 to 2^-24)
-__device__ __forceinline__ u32x2 c1_record(float v)
-{
-    // seven VALU instructions: v_cvt_pk_bf16_f32 rounds two floats into one dword, and the HIGH half of a dword is already the
-    // float value of that bf16 (one v_and), so each residual costs an and + a subtract
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const unsigned int d11 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)v, (__bf16)v});          // x1 | x1
-    const float r1 = v - __builtin_bit_cast(float, d11 & 0xffff0000u);
-    const unsigned int d0 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)v, (__bf16)r1});          // x1 | x2
-    const float r2 = r1 - __builtin_bit_cast(float, d0 & 0xffff0000u);
-    const unsigned int d1 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)r2, (__bf16)v});          // x3 | x1
-    return u32x2{d0, d1};
-}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -160,6 +145,15 @@ __device__ __forceinline__ unsigned int c12_absmax8(const f32x4& a, const f32x4&
     const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
     const float m = fmaxf(fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(a2), fabsf(a3))), fmaxf(fmaxf(fabsf(b0), fabsf(b1)), fmaxf(fabsf(b2), fabsf(b3))));
     return __builtin_bit_cast(unsigned int, m);
+}
+
+// A crop with a non-finite pixel is screened as if that pixel were 0: its NaN / Inf must not reach the LDS images other cells of this
+// persistent workgroup are built in (zero weights against neighbouring records would turn a stale NaN into a NaN of the NEXT cell).
+// The cell's error sums (conv67 reads x itself) come out NaN / Inf anyway, and finalize_kernel then reports NaN scores for it.
+__device__ __forceinline__ void c12_sanitize(f32x4& v)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_fabsf(v[j]) <= 3.402823466e38f ? v[j] : 0.0f;
 }
 
 // C2H: conv2's contraction M = V U (P3) as a TWO-term fp16 split on v_mfma_f32_16x16x32_f16 (conv_wino_up.hip, conv67_h2_kernel, has
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                                                               unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3,
                                                               float p1a, float p1b, float inv_sw, float inv_sw1)
 {
-    static_assert(!C1H || (C1X3 && C2H), "conv1 as an fp16 split rides on the scale plumbing of C2H and the record slots of C1X3");
+    static_assert(C1X3 == C2H && C2H == C1H, "two forms: everything on fp32 MFMAs, or conv1 and conv2 as fp16 splits");
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ring = (float*)(smem + OFF_RING);
@@ -232,14 +226,14 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
     }
     if constexpr (C1H) {
         for (int i = tid; i < (2 * 2 * 64 * 16) / 4; i += NTHR) ((unsigned int*)(smem + OFF_B1X))[i] = w1x3[i];
-    } else if constexpr (C1X3) {
-        for (int i = tid; i < (2 * 3 * 64 * 16 + 32 * 4) / 4; i += NTHR) ((unsigned int*)(smem + OFF_B1X))[i] = w1x3[i];
     }
     {
         const int srow = tid >> 4, sc16 = tid & 15;
         const float* src = x + (size_t)blockIdx.x * 4096 + srow * 64 + 4 * sc16;
         float* dst = inp + (srow + 1) * INP_STRIDE + 4 + 4 * sc16;
-        const f32x4 c0 = *(const f32x4*)src, c1 = *(const f32x4*)(src + 32 * 64);
+        f32x4 c0 = *(const f32x4*)src, c1 = *(const f32x4*)(src + 32 * 64);
+        c12_sanitize(c0);
+        c12_sanitize(c1);
         *(f32x4*)dst = c0;
         *(f32x4*)(dst + 32 * INP_STRIDE) = c1;
         if constexpr (C2H) {
@@ -282,11 +276,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             *(unsigned int*)(smem + t * 4) = rec(v0);
             *(unsigned int*)(smem + (t + NTHR) * 4) = rec(v1);
             if (t + 2 * NTHR < nrec) *(unsigned int*)(smem + (t + 2 * NTHR) * 4) = rec(v2);
-            return;
         }
-        *(u32x2*)(smem + t * 8) = c1_record(v0);
-        *(u32x2*)(smem + (t + NTHR) * 8) = c1_record(v1);
-        if (t + 2 * NTHR < nrec) *(u32x2*)(smem + (t + 2 * NTHR) * 8) = c1_record(v2);
     };
     if constexpr (C1X3) {
         build_records(0, tid);
@@ -364,74 +354,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
                     f32x4 acc0 = conv_row(frag(0)), acc1 = conv_row(frag(1));                     // q = 1: conv rows 0, 1
                     mfma_result_fence(acc0, acc1);
-                    float* const row = ring + RING_ROWF + pwoff;
-                    row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
-                    row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
-                }
-                p1_rows4(8 * g + 2, false);
-                p1_rows4(8 * g + 6, g == 3);
-            } else if constexpr (C1X3) {
-                // A fragment of lane (pixel li, kq): the records of taps 2 kq and 2 kq + 1 (tap t = (t / 3, t % 3)) of its pixel
-                const int tA = 2 * kq2, tB = 2 * kq2 + 1;
-                const int offA = ((tA / 3) * INP_STRIDE + (tA % 3) + 16 * xt + li2 + 3) * 8;
-                const int offB = ((tB / 3) * INP_STRIDE + (tB % 3) + 16 * xt + li2 + 3) * 8;
-                const bf16x8 Bx1 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 0) * 64 + l2) * 16);
-                const bf16x8 Bx2 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 1) * 64 + l2) * 16);
-                const bf16x8 Bx3 = *(const bf16x8*)(smem + OFF_B1X + ((s1 * 3 + 2) * 64 + l2) * 16);
-                const int c1 = s1 * 16 + li2;
-                const float w9 = *(const float*)(smem + OFF_W9 + c1 * 4);
-                f32x4 e1v = *(const f32x4*)(smem + OFF_EP1 + c1 * 16);                 // bias, bn scale, bn shift, sign
-                if constexpr (C2H) { e1v[1] *= vscale; e1v[2] *= vscale; }              // the ring holds S p1 (exact: S is a power of two)
-                const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
-                // tap (2,2) of the lane's four pixels 4 kq + r (D layout): crop floats (row + 2, 16 xt + 4 kq + r + 5)
-                const int off9 = 2 * INP_STRIDE + 16 * xt + 4 * kq2 + 5;
-                const int row0 = g == 0 ? 0 : 16 * g + 2;                                // first INP row of this group's records
-                auto frag = [&](int inp_row) -> bf16x8 {
-                    const char* b = smem + (inp_row - row0) * (INP_STRIDE * 8);
-                    const u32x2 ra = *(const u32x2*)(b + offA), rb = *(const u32x2*)(b + offB);
-                    return __builtin_bit_cast(bf16x8, u32x4{ra[0], ra[1], rb[0], rb[1]});
-                };
-                auto conv_row = [&](const bf16x8& a) -> f32x4 {
-                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx3, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx2, acc, 0, 0, 0);
-                    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bx1, acc, 0, 0, 0);
-                };
-                auto tap9 = [&](f32x4& acc, int inp_row) {
-                    const float* p9 = inp + inp_row * INP_STRIDE + off9;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(p9[r], w9, acc[r]);
-                };
-                // four pooled rows at a time, in stages: all fragment reads, the 16 MFMAs, the ninth tap, the four epilogues
-                auto p1_rows4 = [&](int qb, bool last_is_zero_row) {
-                    bf16x8 a0[4], a1[4];
-                    int rr[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int q = (i == 3 && last_is_zero_row) ? qb + 2 : qb + i;        // a valid row; its result is discarded
-                        rr[i] = 2 * (q - 1);
-                        a0[i] = frag(rr[i]);
-                        a1[i] = frag(rr[i] + 1);
-                    }
-                    f32x4 acc0[4], acc1[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { acc0[i] = conv_row(a0[i]); acc1[i] = conv_row(a1[i]); }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { tap9(acc0[i], rr[i]); tap9(acc1[i], rr[i] + 1); }     // compiler-visible fmas on every accumulator: they carry the wait states
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float* const row = ring + ((qb + i) % RING_SLOTS) * RING_ROWF + pwoff;
-                        float v0 = pool_post(acc0[i][0], acc0[i][1], acc1[i][0], acc1[i][1], e1v[3], e1v[0], e1v[1], e1v[2]);
-                        float v1 = pool_post(acc0[i][2], acc0[i][3], acc1[i][2], acc1[i][3], e1v[3], e1v[0], e1v[1], e1v[2]);
-                        if (i == 3 && last_is_zero_row) v0 = v1 = 0.0f;                     // q = 33: the bottom zero row
-                        row[0] = v0;
-                        row[32] = v1;
-                    }
-                };
-                if (g == 0) {
-                    if (t2 < 256) *(f32x4*)(ring + 32 + 4 * t2) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // q = 0 -> slot 0
-                    f32x4 acc0 = conv_row(frag(0)), acc1 = conv_row(frag(1));                      // q = 1: conv rows 0, 1
-                    tap9(acc0, 0);
-                    tap9(acc1, 1);
                     float* const row = ring + RING_ROWF + pwoff;
                     row[0] = pool_post(acc0[0], acc0[1], acc1[0], acc1[1], e1v[3], e1v[0], e1v[1], e1v[2]);
                     row[32] = pool_post(acc0[2], acc0[3], acc1[2], acc1[3], e1v[3], e1v[0], e1v[1], e1v[2]);
@@ -534,6 +456,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 }
                 if (g == 3 && has_next) {   // the crop buffer is dead since the barrier above
                     float* dst = inp + ((t2 >> 4) + 1) * INP_STRIDE + 4 + 4 * (t2 & 15);
+                    c12_sanitize(stg0);
+                    c12_sanitize(stg1);
                     *(f32x4*)dst = stg0;
                     *(f32x4*)(dst + 32 * INP_STRIDE) = stg1;
                     if constexpr (C2H) {
@@ -818,46 +742,6 @@ size_t pack_conv12_conv1_fragments(const float* hwio /* [3][3][1][32] */, const 
     return total;
 }
 
-// conv1 for the bf16 form of P1 (C1X3): per (slice, MFMA m, lane (li, kq)) eight bf16 = the B slots of taps 2 kq and 2 kq + 1
-// against the records [x1, x2, x3, x1]: m = 0: [w1, 0, 0, 0], m = 1: [w2, w1, 0, 0], m = 2: [0, w2, w1, w3] (w = w1 + w2 + w3, bf16 each; negated for the
-// filters with a negative BN scale, as above); then the fp32 weights of tap (2,2) per channel.  Returns 32-bit words.
-size_t pack_conv12_conv1_x3(const float* hwio /* [3][3][1][32] */, const float* bn_scale /* [32] */, unsigned int* dst)
-{
-    const size_t total = (size_t)(2 * 3 * 64 * 16 + 32 * 4) / 4;
-    if (!dst) return total;
-    auto rne = [](float v) -> unsigned short {
-        unsigned int u;
-        memcpy(&u, &v, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
-    };
-    auto val = [](unsigned short h) -> float {
-        const unsigned int u = (unsigned int)h << 16;
-        float v;
-        memcpy(&v, &u, 4);
-        return v;
-    };
-    unsigned short* d16 = (unsigned short*)dst;
-    for (int nsl = 0; nsl < 2; ++nsl)
-        for (int m = 0; m < 3; ++m)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j) {
-                    const int li = lane & 15, kq = lane >> 4, tap = 2 * kq + (j >> 2), slot = j & 3, co = nsl * 16 + li;
-                    float w = hwio[(size_t)tap * 32 + co];
-                    if (bn_scale[co] < 0.0f) w = -w;
-                    const unsigned short w1 = rne(w);
-                    const float r1 = w - val(w1);
-                    const unsigned short w2 = rne(r1);
-                    const unsigned short w3 = rne(r1 - val(w2));
-                    const unsigned short tab[3][4] = {{w1, 0, 0, 0}, {w2, w1, 0, 0}, {0, w2, w1, w3}};
-                    d16[(((size_t)nsl * 3 + m) * 64 + lane) * 8 + j] = tab[m][slot];
-                }
-    float* w9 = (float*)(dst + (2 * 3 * 64 * 16) / 4);
-    for (int co = 0; co < 32; ++co) w9[co] = bn_scale[co] < 0.0f ? -hwio[(size_t)8 * 32 + co] : hwio[(size_t)8 * 32 + co];
-    return total;
-}
-
 // conv1 for the fp16 form of P1 (C1H): per (slice, MFMA m, lane (li, kq)) eight fp16 = the B slots (pair p, plane) of the lane's four
 // record positions {0, 1, 72, 73} from its base {0, 2, 144, 146}[kq]: the taps of conv12_fused_kernel's comment, zero elsewhere.
 // m = 0: [w_hi, 0] per tap, m = 1: [w_lo, w_hi]; w scaled by S_w1 (a power of two), negated for filters with a negative BN scale.
@@ -891,20 +775,18 @@ unsigned long long* g_c12_diag = nullptr;
 int g_c12_diag_blocks = 0;
 
 hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float* ep1, const float* ufrag, const float* ep2, float* p2,
-                               int64_t n_cells, hipStream_t stream, const unsigned int* w1x3, const unsigned int* ufrag_h2, float p1a, float p1b,
+                               int64_t n_cells, hipStream_t stream, const unsigned int* ufrag_h2, float p1a, float p1b,
                                float inv_sw, const unsigned int* w1h2, float inv_sw1)
 {
     static int cus = 0;
-    static const bool diag = getenv("CS_C12_DIAG") != nullptr;
+    static const bool diag = getenv("CS_C12_DIAG") != nullptr;       // tools/c12_diag.py: the stamped build, never for results
     if (!cus) {
         hipError_t e;
-#define C12_ATTR(D, X, H)                                                                                                           \
-    if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<D, X, H>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
-        C12_ATTR(false, false, false); C12_ATTR(true, false, false); C12_ATTR(false, true, false); C12_ATTR(true, true, false);
-        C12_ATTR(false, true, true); C12_ATTR(true, true, true);
+#define C12_ATTR(...)                                                                                                                \
+    if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
+        C12_ATTR(false, false, false, false); C12_ATTR(true, false, false, false);
+        C12_ATTR(false, true, true, true); C12_ATTR(true, true, true, true);
 #undef C12_ATTR
-        if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e;
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -915,21 +797,19 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
         }
     }
     if (n_cells <= 0) return hipSuccess;
+    if ((w1h2 == nullptr) != (ufrag_h2 == nullptr)) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);      // one workgroup per CU (LDS-bound), persistent over cells
     unsigned long long* const dp = diag ? g_c12_diag : nullptr;
-#define C12_GO(D, X, H, UF)                                                                                                         \
-    hipLaunchKernelGGL((conv12_fused_kernel<D, X, H>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, UF, ep2, p2,      \
-                       (long)n_cells, dp, w1x3, p1a, p1b, inv_sw, 1.0f)
-    if (w1h2 && ufrag_h2) {      // conv1 and conv2 as fp16 splits
-        if (diag)
-            hipLaunchKernelGGL((conv12_fused_kernel<true, true, true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1,
-                               (const float*)ufrag_h2, ep2, p2, (long)n_cells, dp, w1h2, p1a, p1b, inv_sw, inv_sw1);
-        else
-            hipLaunchKernelGGL((conv12_fused_kernel<false, true, true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1,
-                               (const float*)ufrag_h2, ep2, p2, (long)n_cells, dp, w1h2, p1a, p1b, inv_sw, inv_sw1);
-    } else if (w1x3 && ufrag_h2) { if (diag) C12_GO(true, true, true, (const float*)ufrag_h2); else C12_GO(false, true, true, (const float*)ufrag_h2); }   // conv2 as an fp16 split
-    else if (w1x3) { if (diag) C12_GO(true, true, false, ufrag); else C12_GO(false, true, false, ufrag); }       // conv1 on bf16 MFMAs
-    else           { if (diag) C12_GO(true, false, false, ufrag); else C12_GO(false, false, false, ufrag); }
+#define C12_GO(UF, W1, ISW1, ...)                                                                                                    \
+    hipLaunchKernelGGL((conv12_fused_kernel<__VA_ARGS__>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, UF, ep2, p2,   \
+                       (long)n_cells, dp, W1, p1a, p1b, inv_sw, ISW1)
+    if (w1h2) {      // CS_PRECISION_SPLIT16: conv1 and conv2 as fp16 splits
+        if (diag) C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, true, true, true, true);
+        else C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, false, true, true, true);
+    } else {         // CS_PRECISION_FP32_EXACT
+        if (diag) C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, true, false, false, false);
+        else C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, false, false, false, false);
+    }
 #undef C12_GO
     return hipGetLastError();
 }

@@ -1,246 +1,34 @@
-// conv45_bf16x3.hip -- conv4 (and, below, conv5) of the reference autoencoder: conv4 (CAE_improved_modeltrain.py:203-205: 3x3 'same',
-// 32 -> 32 on the 8x8 bottleneck, bias -> ReLU -> BatchNormalization) with the fp32 contraction carried by
-// the bf16 matrix pipe: every fp32 operand is split into three bf16 terms (x = x1 + x2 + x3 exactly to 2^-24:
-// x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), each residual exact in fp32) and the product
-// a*b is taken as the six partial products of weight 2^0 .. 2^-16
-//      a1 b1 | a1 b2, a2 b1 | a1 b3, a2 b2, a3 b1
-// (each product exact in fp32; the three dropped ones are below 2^-24 of |a b|).  One MFMA carries ONE of these
-// magnitudes: measured on the MI355X (conv1 in conv12_fused.hip), an MFMA that sums terms 2^16 apart inside one
-// instruction loses part of the small ones.
-// v_mfma_f32_16x16x32_bf16 does 16,384 multiply-adds in ~16 cycles where v_mfma_f32_16x16x4_f32 does 1,024 in
-// 32, so six of them per 32 channels cost 96 cycles against 256: the contraction runs 2.7x faster at the same
-// fp32 error class (tests/study_split_bf16.py; measured against the oracle by tests/test_gpu_parity.py at the
-// unchanged tolerances).  This layer was the hardware proof of the technique (conv4 against a float64 conv of the
-// same p3: 2.4e-7 of the range, the fp32 MFMA chain 8.0e-7); DESIGN.md section 3g lists where else it runs and why
-// the Winograd layers keep the fp32 instructions.
+// conv45_h2.hip -- conv4 and conv5 of the reference autoencoder (CAE_improved_modeltrain.py:203-208) with the fp32 contraction as a
+// TWO-term fp16 split on v_mfma_f32_16x16x32_f16 (CS_PRECISION_SPLIT16):
+//   conv4_h2_kernel   3x3 'same' 32 -> 32 on the 8x8 bottleneck, bias -> ReLU -> BatchNormalization (stage taps, CS_DEBUG_NO_FUSE45)
+//   conv5_h2_kernel   UpSampling2D -> 3x3 'same' 32 -> 64 -> ReLU -> BatchNormalization, the upsample folded into four 2x2-tap
+//                     phase convs over the stored grid (4/9 of the multiply-adds)
+//   conv45_h2_kernel  the two as one kernel, a4 in LDS: what cs_screen runs
 //
 // Mapping (D[16 pixels][16 couts] += A[16 pixels][32 ch] * B[32 ch][16 couts], one MFMA per tap and product):
 //   lane l: A = 8 channels 8(l>>4)..+7 of pixel l&15 of the tile (two rows of eight), B = the same 8 channels of
-//   cout l&15 of the wave's slice.  A workgroup (4 waves) owns one cell at a time: wave = (16-cout slice, half of
-//   the cell's four tiles).  The weights (9 taps x 3 planes x 4 VGPRs = 108 registers) stay in registers; the
-//   cell is split ONCE per element when it is staged (5.5 VALU instructions per value) into three bf16 planes in
-//   LDS with a zero halo, pixel stride 64 B and row stride 672 B (the lane groups of a ds_read_b128 land on
-//   16 distinct 16-byte slots), and every tap's A fragment is one ds_read_b128 per plane.
+//   cout l&15 of the wave's slice.  The weights stay in registers; the cell is split ONCE per element when it is staged
+//   into two fp16 planes in LDS with a zero halo, pixel stride 64 B and row stride 672 B (the lane groups of a ds_read_b128
+//   land on 16 distinct 16-byte slots), and every tap's A fragment is one ds_read_b128 per plane.
 #include "common.hpp"
 
 #include <cstring>
 
 namespace cs {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 namespace {
 
 constexpr int G = 8;                      // the bottleneck grid
 constexpr int CH = 32;                    // channels in = channels out
 constexpr int WP = G + 2;                 // staged row length (halo)
-constexpr int PXB = 64;                   // bytes per staged pixel and plane: 32 bf16
+constexpr int PXB = 64;                   // bytes per staged pixel and plane: 32 fp16
 constexpr int ROWB = WP * PXB + 32;       // bytes per staged row.  With 4 and 42 16-byte slots per pixel and row every lane group of a
                                           // ds_read_b128 ({0-3,12-15,20-27}, ...: pixels x 0-3 of row 0 and 4-7 of row 1 at kq, the other
                                           // eight at kq + 1) lands on 16 distinct slots (enumerated; 80 B / 896 B was 2-way everywhere)
 constexpr int PLANE = WP * ROWB;          // 6,720 B
-constexpr int LDS_BYTES = 3 * PLANE;      // 20,160 B
 constexpr int WG_PER_CU = 2;
 
-__device__ __forceinline__ void split4(const f32x4& v, bf16x4& h1, bf16x4& h2, bf16x4& h3)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 a1 = (__bf16)v[j];
-        const float r1 = v[j] - (float)a1;
-        const __bf16 a2 = (__bf16)r1;
-        const float r2 = r1 - (float)a2;
-        h1[j] = a1;
-        h2[j] = a2;
-        h3[j] = (__bf16)r2;
-    }
-}
-
-__global__ __launch_bounds__(256, WG_PER_CU) void conv4_bf16x3_kernel(const float* __restrict__ in, const bf16x8* __restrict__ wfrag,
-                                                                     const float* __restrict__ ep, float* __restrict__ out,
-                                                                     long n_cells)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = wave & 1;           // couts 16 slice .. +15
-    const int th = wave >> 1;             // tiles 2 th, 2 th + 1 (rows 4 th .. 4 th + 3)
-    const int li = lane & 15, kq = lane >> 4;
-
-    bf16x8 B[9][3];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) B[t][p] = wfrag[((slice * 9 + t) * 3 + p) * 64 + lane];
-    const int co = slice * 16 + li;
-    const float bias = ep[co], bns = ep[CH + co], bnt = ep[2 * CH + co];
-
-    // zero the planes once: the interior is rewritten for every cell, the halo stays zero
-    for (int i = tid; i < LDS_BYTES / 16; i += 256) *(f32x4*)(smem + i * 16) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    long cell = blockIdx.x;
-    if (cell >= n_cells) return;
-    f32x4 stg[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) stg[k] = *(const f32x4*)(in + (size_t)cell * (G * G * CH) + (tid + 256 * k) * 4);
-    __syncthreads();
-
-    // staged address of this thread's two float4s: element idx = (pixel, 4-channel group)
-    int woff[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int idx = tid + 256 * k, px = idx >> 3, c4 = idx & 7;
-        woff[k] = ((px >> 3) + 1) * ROWB + ((px & 7) + 1) * PXB + c4 * 8;
-    }
-    // A base of tile 2 th (tile 2 th + 1 sits two staged rows below): tap (dy, dx) adds dy ROWB + dx PXB
-    const int abase = (4 * th + (li >> 3)) * ROWB + (li & 7) * PXB + kq * 16;
-
-    for (; cell < n_cells; cell += gridDim.x) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            bf16x4 h1, h2, h3;
-            split4(stg[k], h1, h2, h3);
-            *(bf16x4*)(smem + woff[k]) = h1;
-            *(bf16x4*)(smem + PLANE + woff[k]) = h2;
-            *(bf16x4*)(smem + 2 * PLANE + woff[k]) = h3;
-        }
-        __syncthreads();
-        const long ncell = cell + gridDim.x;
-        if (ncell < n_cells) {     // in flight during the MFMA phase
-#pragma unroll
-            for (int k = 0; k < 2; ++k) stg[k] = *(const f32x4*)(in + (size_t)ncell * (G * G * CH) + (tid + 256 * k) * 4);
-        }
-
-        f32x4 hi[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-        f32x4 lo[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-        f32x4 lw[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};     // three accumulation chains per tile: weights 1, 2^-8, 2^-16
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * ROWB + (tap % 3) * PXB;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const char* a = smem + abase + toff + t * (2 * ROWB);
-                const bf16x8 a1 = *(const bf16x8*)a;
-                const bf16x8 a2 = *(const bf16x8*)(a + PLANE);
-                const bf16x8 a3 = *(const bf16x8*)(a + 2 * PLANE);
-                hi[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][0], hi[t], 0, 0, 0);
-                lo[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][1], lo[t], 0, 0, 0);
-                lo[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[tap][0], lo[t], 0, 0, 0);
-                lw[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[tap][1], lw[t], 0, 0, 0);
-                lw[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][2], lw[t], 0, 0, 0);
-                lw[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, B[tap][0], lw[t], 0, 0, 0);
-            }
-        }
-        // D[row = 4 kq + r][col = li]: pixel 16 tile + 4 kq + r of the cell, cout co
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float* o = out + ((size_t)cell * (G * G) + 16 * (2 * th + t) + 4 * kq) * CH + co;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = hi[t][r] + (lo[t][r] + lw[t][r]);
-                v = fmaxf(v + bias, 0.0f);
-                o[r * CH] = fmaf(v, bns, bnt);
-            }
-        }
-        __syncthreads();           // every wave is done reading the planes
-    }
-}
-
-
-// ---- conv5 (CAE_improved_modeltrain.py:206-208: UpSampling2D -> 3x3 'same' 32 -> 64 -> ReLU -> BatchNormalization) --------------
-// The upsample is folded as everywhere else (four output phases (a,b), each a 2x2-tap conv over the STORED 8x8 grid with the
-// taps that share a stored pixel pre-summed: 4/9 of the multiply-adds), and the contraction runs as six bf16 products like
-// conv4's.  The staged input is conv4's layout exactly (three bf16 planes of the 8x8x32 cell with a zero halo).  A workgroup
-// is 8 waves = 4 phases x 2 halves of the 64 filters; a wave keeps its phase's weights for its two 16-filter slices in
-// registers (4 taps x 2 slices x 3 planes x 4 VGPRs = 96) and walks the cell's four 16-pixel tiles: one A fragment (three
-// ds_read_b128) feeds 12 MFMAs.
 constexpr int C5_OUT = 64;
-
-__global__ __launch_bounds__(512, 2) void conv5_bf16x3_kernel(const float* __restrict__ in, const bf16x8* __restrict__ wfrag,
-                                                              const float* __restrict__ ep, float* __restrict__ out, long n_cells)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = wave >> 1, pa = ph >> 1, pb = ph & 1;      // output phase (a,b)
-    const int sp = wave & 1;                                  // filters 32 sp .. 32 sp + 31
-    const int li = lane & 15, kq = lane >> 4;
-
-    bf16x8 B[4][2][3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) B[t][k][p] = wfrag[(((wave * 4 + t) * 2 + k) * 3 + p) * 64 + lane];
-    float bias[2], bns[2], bnt[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int co = (2 * sp + k) * 16 + li;
-        bias[k] = ep[co]; bns[k] = ep[C5_OUT + co]; bnt[k] = ep[2 * C5_OUT + co];
-    }
-
-    for (int i = tid; i < LDS_BYTES / 16; i += 512) *(f32x4*)(smem + i * 16) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    long cell = blockIdx.x;
-    if (cell >= n_cells) return;
-    f32x4 stg = *(const f32x4*)(in + (size_t)cell * (G * G * CH) + tid * 4);
-    __syncthreads();
-    // staged address of this thread's float4: element tid = (pixel, 4-channel group)
-    const int woff = ((tid >> 6) + 1) * ROWB + (((tid >> 3) & 7) + 1) * PXB + (tid & 7) * 8;
-    // A base of tile 0 (tile t sits 2 t staged rows below): staged (ys + a + ry, xs + b + rx), tap (ry, rx) adds ry ROWB + rx PXB
-    const int abase = ((li >> 3) + pa) * ROWB + ((li & 7) + pb) * PXB + kq * 16;
-
-    for (; cell < n_cells; cell += gridDim.x) {
-        {
-            bf16x4 h1, h2, h3;
-            split4(stg, h1, h2, h3);
-            *(bf16x4*)(smem + woff) = h1;
-            *(bf16x4*)(smem + PLANE + woff) = h2;
-            *(bf16x4*)(smem + 2 * PLANE + woff) = h3;
-        }
-        __syncthreads();
-        const long ncell = cell + gridDim.x;
-        if (ncell < n_cells) stg = *(const f32x4*)(in + (size_t)ncell * (G * G * CH) + tid * 4);     // in flight during the MFMA phase
-
-        float* obase = out + (((size_t)cell * (2 * G) + pa) * (2 * G) + pb) * C5_OUT + (2 * sp) * 16 + li;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-#pragma unroll
-            for (int tap = 0; tap < 4; ++tap) {
-                const char* a = smem + abase + t * (2 * ROWB) + (tap >> 1) * ROWB + (tap & 1) * PXB;
-                const bf16x8 a1 = *(const bf16x8*)a;
-                const bf16x8 a2 = *(const bf16x8*)(a + PLANE);
-                const bf16x8 a3 = *(const bf16x8*)(a + 2 * PLANE);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][k][2], acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[tap][k][1], acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, B[tap][k][0], acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][k][1], acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[tap][k][0], acc[k], 0, 0, 0);
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[tap][k][0], acc[k], 0, 0, 0);
-                }
-            }
-            // D[row = 4 kq + r][col = li]: stored pixel i = 4 kq + r of tile t = (2 t + (i >> 3), i & 7) -> output (2 ys + a, 2 xs + b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * kq + r, ys = 2 * t + (i >> 3), xs = i & 7;
-                float* o = obase + ((size_t)(2 * ys) * (2 * G) + 2 * xs) * C5_OUT;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float v = fmaxf(acc[k][r] + bias[k], 0.0f);
-                    o[16 * k] = fmaf(v, bns[k], bnt[k]);
-                }
-            }
-        }
-        __syncthreads();           // every wave is done reading the planes
-    }
-}
 
 // ---- conv4 and conv5 with the contraction as a TWO-term fp16 split (three products): conv_wino_up.hip (conv67_h2_kernel) has the
 // algebra and the hardware facts.  x = hi + lo in fp16 after an exact power-of-two scale per CELL (the whole 8x8x32 cell is
@@ -634,107 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv45_h2_kernel(const float* __restri
     }
 }
 
-uint16_t bf16_rne(float x)
-{
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-float bf16_val(uint16_t h)
-{
-    const uint32_t u = (uint32_t)h << 16;
-    float x;
-    memcpy(&x, &u, 4);
-    return x;
-}
-
 }  // namespace
-
-// [slice 2][tap 9][plane 3][lane 64][8] bf16: element j of lane (li, kq) = plane p of W[tap][ci = 8 kq + j][co = 16 slice + li]
-size_t pack_conv4_bf16x3(const float* hwio, uint16_t* dst)
-{
-    const size_t n = (size_t)2 * 9 * 3 * 64 * 8;
-    if (!dst) return n;
-    for (int s = 0; s < 2; ++s)
-        for (int t = 0; t < 9; ++t)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int li = l & 15, kq = l >> 4;
-                    const float w = hwio[((size_t)t * CH + 8 * kq + j) * CH + 16 * s + li];
-                    const uint16_t w1 = bf16_rne(w);
-                    const float r1 = w - bf16_val(w1);
-                    const uint16_t w2 = bf16_rne(r1);
-                    const float r2 = r1 - bf16_val(w2);
-                    const uint16_t w3 = bf16_rne(r2);
-                    const uint16_t pl[3] = {w1, w2, w3};
-                    for (int p = 0; p < 3; ++p) dst[((((size_t)s * 9 + t) * 3 + p) * 64 + l) * 8 + j] = pl[p];
-                }
-    return n;
-}
-
-hipError_t launch_conv4_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
-{
-    if (n_cells <= 0) return hipSuccess;
-    // persistent grid = the workgroups the chip holds at once (as conv_mfma.hip's launchers)
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, cus = 0, per_cu = 0;
-        hipError_t e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv4_bf16x3_kernel, 256, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        resident = cus * (per_cu < 1 ? 1 : per_cu);
-    }
-    const long grid = n_cells < resident ? n_cells : resident;
-    hipLaunchKernelGGL(conv4_bf16x3_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, in, (const bf16x8*)wfrag, ep, out,
-                       (long)n_cells);
-    return hipGetLastError();
-}
-
-// conv5's folded weights (pack_generic_folded(32, 64, ...): [phase 4][tap 4][cin 32][cout 64]) as planes in the kernel's order:
-// [wave = phase * 2 + half][tap][slice-in-half 2][plane 3][lane 64][8]: element j = plane of W_eff[phase][tap][8 kq + j][(2 half + k) 16 + li]
-size_t pack_conv5_bf16x3(const float* weff, uint16_t* dst)
-{
-    const size_t n = (size_t)8 * 4 * 2 * 3 * 64 * 8;
-    if (!dst) return n;
-    for (int w = 0; w < 8; ++w)
-        for (int t = 0; t < 4; ++t)
-            for (int k = 0; k < 2; ++k)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int ph = w >> 1, sp = w & 1, li = l & 15, kq = l >> 4;
-                        const float v = weff[((size_t)(ph * 4 + t) * CH + 8 * kq + j) * C5_OUT + (2 * sp + k) * 16 + li];
-                        const uint16_t w1 = bf16_rne(v);
-                        const float r1 = v - bf16_val(w1);
-                        const uint16_t w2 = bf16_rne(r1);
-                        const float r2 = r1 - bf16_val(w2);
-                        const uint16_t pl[3] = {w1, w2, bf16_rne(r2)};
-                        for (int p = 0; p < 3; ++p) dst[((((((size_t)w * 4 + t) * 2 + k) * 3 + p) * 64) + l) * 8 + j] = pl[p];
-                    }
-    return n;
-}
-
-hipError_t launch_conv5_bf16x3(const float* in, const uint16_t* wfrag, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
-{
-    if (n_cells <= 0) return hipSuccess;
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, cus = 0, per_cu = 0;
-        hipError_t e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv5_bf16x3_kernel, 512, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        resident = cus * (per_cu < 1 ? 1 : per_cu);
-    }
-    const long grid = n_cells < resident ? n_cells : resident;
-    hipLaunchKernelGGL(conv5_bf16x3_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, in, (const bf16x8*)wfrag, ep, out,
-                       (long)n_cells);
-    return hipGetLastError();
-}
 
 // conv4's weights as two fp16 planes of S_w W: [slice 2][tap 9][plane 2][lane 64][8]; *inv_sw = 1 / S_w
 size_t pack_conv4_f16x2(const float* hwio, uint16_t* dst, float* inv_sw)

@@ -728,8 +728,7 @@ int conv_generic_supported(int H, int W, int cin, int cout, char* why, size_t wh
 // version-2 plan for a layer: SR rows per strip, nmg tile groups x nslw slices = 8 waves, TPW tiles per wave
 static bool gen2_plan(int H, int W, int cin, int cout, int ups, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
 {
-    static const bool off = getenv("CS_GENERIC_V1") != nullptr;
-    if (off || !(cin % 16 == 0 || (cin == 1 && !ups)) || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
+    if (!(cin % 16 == 0 || (cin == 1 && !ups)) || !(W == 16 || W == 32 || W == 64 || W == 128) || cout < 16) return false;
     const int slices = (cout + 15) / 16;
     int ns = 1;
     while (ns * 2 <= slices && ns < 8) ns *= 2;           // largest power of two <= min(slices, 8)
@@ -751,9 +750,8 @@ static bool gen2_plan(int H, int W, int cin, int cout, int ups, int* SR, int* nm
 // folded-upsample plan: nmg in {1, 2, 4} phase groups, every wave owns all TPW = (SR / 2) (Ws / 16) tiles of the strip
 static bool gen2f_plan(int H, int W, int cin, int cout, int* SR, int* nmg, int* nslw, int* tpw, size_t* lds)
 {
-    static const bool off = getenv("CS_GENERIC_V1") != nullptr || getenv("CS_GENERIC_NO_FOLD") != nullptr;
     const int Ws = W / 2;
-    if (off || cin % 16 != 0 || !(Ws == 16 || Ws == 32 || Ws == 64) || cout < 32) return false;
+    if (cin % 16 != 0 || !(Ws == 16 || Ws == 32 || Ws == 64) || cout < 32) return false;
     const int slices = (cout + 15) / 16;
     int ns = 2;
     while (ns * 2 <= slices && ns < 8) ns *= 2;           // 2, 4 or 8 slices per pass -> 4, 2 or 1 phase groups
@@ -813,9 +811,7 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
     g.ups = ups; g.epi = epi;
     g.ps = cin == 1 ? 1 : cin + 4;                        // odd number of 16-B slots per pixel
     hipError_t e = hipSuccess;
-    static const bool v1_only = getenv("CS_GENERIC_V1") != nullptr;
-    static const bool no_fold = getenv("CS_GENERIC_NO_FOLD") != nullptr;
-    if (!v1_only && !no_fold && cout == 1 && epi == GEN_EPI_SIGMOID && ups && w_folded && cin % 4 == 0 && cin >= 4) {
+    if (cout == 1 && epi == GEN_EPI_SIGMOID && ups && w_folded && cin % 4 == 0 && cin >= 4) {
         const int Hs = H / 2, Ws = W / 2;
         const int SRS = Hs % 4 == 0 ? 4 : (Hs % 2 == 0 ? 2 : 1);
         const size_t lds = ((size_t)(SRS + 2) * (Ws + 2) * g.ps + 16 * cin) * sizeof(float);
@@ -830,7 +826,7 @@ hipError_t launch_conv_generic(const float* in, const float* w_hwio, const float
             return hipGetLastError();
         }
     }
-    if (!v1_only && cout == 1 && epi == GEN_EPI_SIGMOID && cin % 4 == 0 && cin >= 4) {
+    if (cout == 1 && epi == GEN_EPI_SIGMOID && cin % 4 == 0 && cin >= 4) {
         // the 1-filter last conv on the vector ALU: strips of 4 conv rows
         const int SR = H % 4 == 0 ? 4 : 2, Ws = ups ? W / 2 : W, R = ups ? SR / 2 + 2 : SR + 2;
         const size_t lds = ((size_t)R * (Ws + 2) * g.ps + 9 * cin) * sizeof(float);

@@ -489,8 +489,6 @@ bool x3f_plan(int H, int W, int cin, int cout, int* SR, int* nmg, int* nslw, int
 
 int conv_generic_x3_takes(int H, int W, int cin, int cout, int ups)
 {
-    static const bool off = getenv("CS_NO_BF16X3") != nullptr || getenv("CS_GENERIC_V1") != nullptr;
-    if (off) return 0;
     int SR, nmg, nslw, tpw;
     size_t lds;
     return (ups ? x3f_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds) : x3_plan(H, W, cin, cout, &SR, &nmg, &nslw, &tpw, &lds)) ? 1 : 0;
@@ -597,8 +595,7 @@ hipError_t launch_conv_generic_x3(const float* in, const uint16_t* wplanes, cons
 // the last conv: plan (stored rows per strip, tiles, T pitch, LDS bytes) or false
 static bool last_x3_plan(int H, int W, int cin, int* SRS, int* NT, int* P, size_t* lds)
 {
-    static const bool off = getenv("CS_NO_BF16X3") != nullptr || getenv("CS_GENERIC_V1") != nullptr || getenv("CS_GENERIC_NO_FOLD") != nullptr;
-    if (off || !(cin == 32 || cin == 64) || H % 2 || W % 2) return false;
+    if (!(cin == 32 || cin == 64) || H % 2 || W % 2) return false;
     const int Hs = H / 2, Ws = W / 2, psb = 6 * cin + 32;
     for (int srs = 8; srs >= 1; srs /= 2) {
         if (Hs % srs) continue;

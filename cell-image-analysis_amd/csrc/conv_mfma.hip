@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     // the register file of the cin = 64 layers is full), its count follows from the items the workgroup has walked
     double* const st_acc = (double*)(smem + C::LDS_BYTES) + 2 * threadIdx.x;
     int st_items = 0;
+    // the sums run about a per-lane shift (the lane's first value): a channel whose variance is far below mean^2 would lose
+    // its M2 to the rounding of the squares otherwise (v - shift is exact for values near the shift)
+    float st_c = 0.0f;
+    bool st_set = false;
     if constexpr (C::EPI == EPI_RELU) { if (stats_part) { st_acc[0] = 0.0; st_acc[1] = 0.0; } }
     const long total = n_cells * C::NSTRIP;
     const long first = blockIdx.x;
@@ -490,7 +494,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                 float* o = out + (((size_t)cell * C::HO + yo) * C::WO + xo) * C::COUT + co;
                 pooled_store(acc0, acc1, o);
             } else {
-                float ps = 0.0f, pq = 0.0f;              // the pair's 8 values in fp32, then into the double accumulators
+                float ps = 0.0f, pq = 0.0f;              // the pair's 8 values (minus the shift) in fp32, then into the double accumulators
+                if constexpr (C::EPI == EPI_RELU) {
+                    if (!st_set) { st_c = post(acc0[0]); st_set = true; }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int qy, qx;
@@ -501,9 +508,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
                     const float v1 = post(acc1[r]);
                     out[(((size_t)cell * C::HO + (y0 + qy)) * C::WO + qx) * C::COUT + co] = v1;
                     if constexpr (C::EPI == EPI_RELU) {
-                        ps += v0 + v1;
-                        pq = fmaf(v0, v0, pq);
-                        pq = fmaf(v1, v1, pq);
+                        const float d0 = v0 - st_c, d1 = v1 - st_c;
+                        ps += d0 + d1;
+                        pq = fmaf(d0, d0, pq);
+                        pq = fmaf(d1, d1, pq);
                     }
                 }
                 if constexpr (C::EPI == EPI_RELU) {
@@ -525,26 +533,33 @@ __global__ __launch_bounds__(256, C::WPS) void conv_mfma_kernel(
     }
     if constexpr (C::EPI == EPI_RELU) {
         if (stats_part) {
-            // lanes kq = 0..3 of a channel, then the NMG waves of the slice (wave = mg * NSL + nsl) in order
-            double st_s = st_acc[0], st_q = st_acc[1];
-            st_s += __shfl_xor(st_s, 16); st_s += __shfl_xor(st_s, 32);
-            st_q += __shfl_xor(st_q, 16); st_q += __shfl_xor(st_q, 32);
+            // per lane {mean, M2} from its shifted sums (double), then Chan's merge of equal counts over the lanes kq = 0..3 of a
+            // channel, then over the NMG waves of the slice (wave = mg * NSL + nsl) in order
+            double nl = (double)st_items * (8.0 * C::PPW);       // a lane writes 8 values per tile pair, PPW pairs per item
+            if (nl == 0.0) nl = 1.0;                             // (never: the grid is at most the number of items)
+            double st_m = (double)st_c + st_acc[0] / nl, st_v = st_acc[1] - st_acc[0] * (st_acc[0] / nl);
+            st_v = st_v > 0.0 ? st_v : 0.0;
+#pragma unroll
+            for (int x = 16; x <= 32; x <<= 1) {
+                const double om = __shfl_xor(st_m, x), ov = __shfl_xor(st_v, x), dm = om - st_m;
+                st_v = (st_v + ov) + dm * dm * (0.5 * nl);
+                st_m = 0.5 * (st_m + om);
+                nl *= 2.0;
+            }
             double* red = (double*)smem;                   // [wave 4][2][16]; the strip is dead (barrier above)
-            if (kq == 0) { red[(wave * 2 + 0) * 16 + li] = st_s; red[(wave * 2 + 1) * 16 + li] = st_q; }
+            if (kq == 0) { red[(wave * 2 + 0) * 16 + li] = st_m; red[(wave * 2 + 1) * 16 + li] = st_v; }
             __syncthreads();
             if (tid < C::COUT) {
                 const int sl = tid >> 4, l16 = tid & 15;
-                double a = 0.0, q = 0.0;
+                double n = 0.0, mu = 0.0, m2 = 0.0;
 #pragma unroll
                 for (int g = 0; g < C::NMG; ++g) {
                     const int w = g * C::NSL + sl;
-                    a += red[(w * 2 + 0) * 16 + l16]; q += red[(w * 2 + 1) * 16 + l16];
+                    const double om = red[(w * 2 + 0) * 16 + l16], ov = red[(w * 2 + 1) * 16 + l16], dm = om - mu, nn = n + nl;
+                    m2 = (m2 + ov) + dm * dm * (n * nl / nn);
+                    mu += dm * (nl / nn);
+                    n = nn;
                 }
-                // a lane writes 8 values per tile pair, PPW pairs per item; 4 lanes per channel, NMG waves per slice
-                const double n = (double)st_items * (8.0 * C::PPW * 4 * C::NMG);
-                const double mu = a / n;
-                double m2 = q - a * mu;
-                m2 = m2 > 0.0 ? m2 : 0.0;
                 float* o = stats_part + (size_t)blockIdx.x * 3 * C::COUT;
                 o[tid] = (float)n;
                 o[C::COUT + tid] = (float)mu;
@@ -608,7 +623,11 @@ static hipError_t launch_cfg(const float* in, const float* wfrag, const float* e
     }
     const long total = (long)n_cells * C::NSTRIP;
     if (total <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    unsigned grid = (unsigned)(total < resident ? total : resident);
+    if (stats_part) {      // one {count, mean, M2} x COUT partial per workgroup in a BN_MAX_PARTS x 3 x 64-float buffer
+        const unsigned cap = (unsigned)(BN_MAX_PARTS * 64 / C::COUT);
+        if (grid > cap) grid = cap;
+    }
     if (stats_parts) *stats_parts = (int)grid;
     hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES + kStatsLds<C>, stream, in, wfrag, ep,
                        out, (long)n_cells, stats_part);

@@ -266,203 +266,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino_cs_kernel(const float* __res
     }
 }
 
-// ---- conv3 with the Winograd-domain contraction on the bf16 matrix pipe ------------------------------------------------
+// ---- conv3 with the Winograd-domain contraction on the 16-bit matrix pipe: the staged-strip layout -----------------------------
 // Same decomposition as conv_wino_cs_kernel<WinoL3> (wave c = column c of the 4x4 transform domain, V[:, c] derived in
-// registers, row fold in registers, column fold through LDS), but M = V U runs as six bf16 products per multiply
-// (conv45_bf16x3.hip has the algebra).  A Winograd form has to split every TRANSFORMED value (5.5 VALU instructions each), and
-// here a value feeds only 32 filters, so the split costs as much issue time as the MFMAs it feeds: 2,048 fp32 MFMAs x 32 cycles
-// become 1,536 bf16 MFMAs x 16 cycles + ~7,700 VALU instructions per cell.  All of U with ONE wave per column is 4 points x 2 slices
-// x 2 channel blocks x 3 planes x 4 = 192 VGPRs per wave, so the kernel runs one wave per SIMD (launch bound 256 threads x 1: up
-// to 512 registers) and nothing overlaps its barriers: 39.4 -> 37.1 ms per 1 M cells, not the 2x of the direct-form layers.
-// A lane (tile li, kq) owns channels {4 kq .. +3} and {16 + 4 kq .. +3} of a 32-channel block: two ds_read_b128 64 B apart,
-// which with a 24-float pad per staged row puts every lane group on 16 distinct 16-byte slots (enumerated).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-
+// registers, row fold in registers, column fold through LDS).  A lane (tile li, kq) owns channels {4 kq .. +3} and
+// {16 + 4 kq .. +3} of a 32-channel block: two ds_read_b128 64 B apart, which with a 24-float pad per staged row puts every
+// lane group on 16 distinct 16-byte slots (enumerated).
 struct W3X {
     using C = WinoL3;
     static constexpr int ROWP = C::WP * C::PS + 24;                 // floats per staged row
     static constexpr int STRIP = C::R * ROWP * 4;                   // 29,952 B
-    static constexpr int LDS = 2 * STRIP + C::XCH;
     static constexpr int NKB = C::CIN / 32;
 };
 
-// eight fp32 values -> the three bf16 planes of an MFMA A operand (v_cvt_pk_bf16_f32 rounds a pair into one dword; the high
-// half of a dword is already that bf16's float value)
-__device__ __forceinline__ void w3x_split8(const f32x4& lo, const f32x4& hi, bf16x8& a1, bf16x8& a2, bf16x8& a3)
-{
-    u32x4v d1, d2, d3;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const float x0 = m < 2 ? lo[2 * m] : hi[2 * m - 4], x1 = m < 2 ? lo[2 * m + 1] : hi[2 * m - 3];
-        const unsigned int p1 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)x0, (__bf16)x1});
-        const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
-        const unsigned int p2 = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)r0, (__bf16)r1});
-        const float s0 = r0 - __builtin_bit_cast(float, p2 << 16), s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
-        d1[m] = p1;
-        d2[m] = p2;
-        d3[m] = __builtin_bit_cast(unsigned int, bf16x2{(__bf16)s0, (__bf16)s1});
-    }
-    a1 = __builtin_bit_cast(bf16x8, d1);
-    a2 = __builtin_bit_cast(bf16x8, d2);
-    a3 = __builtin_bit_cast(bf16x8, d3);
-}
-
-__global__ __launch_bounds__(256, 1) void conv3_wino_x3_kernel(const float* __restrict__ in, const bf16x8* __restrict__ ufrag,
-                                                              const float* __restrict__ ep /* [3][32] */, float* __restrict__ out,
-                                                              long n_cells)
-{
-    using C = WinoL3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const xch = (float*)(smem + 2 * W3X::STRIP);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = transform-domain column
-    const int li = lane & 15, kq = lane >> 4;
-
-    bf16x8 B[4][C::NS][W3X::NKB][3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-            for (int kb = 0; kb < W3X::NKB; ++kb)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) B[r][s][kb][p] = ufrag[(((((size_t)wc * 4 + r) * C::NS + s) * W3X::NKB + kb) * 3 + p) * 64 + lane];
-
-    const int ca = wc == 0 ? 0 : (wc == 2 ? 2 : 1);
-    const int cb = wc == 2 ? 1 : (wc == 3 ? 3 : 2);
-    const float sg = wc == 1 ? 1.0f : -1.0f;
-    const int trow = li / C::TW, tcol = li % C::TW;
-    const int poff = (2 * trow) * W3X::ROWP + (2 * tcol) * C::PS + 4 * kq;
-
-    const int fs = wc % C::NS, rbase = (wc / C::NS) * C::FR;
-    const int co = fs * 16 + li;
-    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
-
-    const long total = n_cells * C::NGRP;
-    const long first = blockIdx.x;
-    if (first >= total) return;
-    const int spx = tid / C::C4, sc4 = tid % C::C4;
-    const int goff = spx * C::CIN + sc4 * 4, loff = (spx + 1) * C::PS + sc4 * 4;
-    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::H * C::W * C::CIN; };
-    auto st_store = [&](float* strip, int y0, int r, f32x4 v) {
-        const int sy = y0 - 1 + r;
-        if (sy < 0 || sy >= C::H) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        *(f32x4*)(strip + r * W3X::ROWP + loff) = v;
-    };
-    for (int i = tid; i < 2 * W3X::STRIP / 16; i += 256) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < C::R; ++r)
-        st_store((float*)smem, (int)(first % C::NGRP) * C::SR, r, wn_load<C>(cell_ptr(first / C::NGRP), (int)(first % C::NGRP) * C::SR, r, goff));
-    __syncthreads();
-
-    f32x4 stg[C::NLD];
-    int buf = 0;
-    for (long item = first; item < total; item += gridDim.x) {
-        const long cell = item / C::NGRP;
-        const int grp = (int)(item % C::NGRP);
-        const long nitem = item + gridDim.x;
-        const bool has_next = nitem < total;
-        const float* strip = (const float*)(smem + buf * W3X::STRIP);
-        float* nstrip = (float*)(smem + (buf ^ 1) * W3X::STRIP);
-        if (has_next) {
-#pragma unroll
-            for (int j = 0; j < C::NLD; ++j) stg[j] = wn_load<C>(cell_ptr(nitem / C::NGRP), (int)(nitem % C::NGRP) * C::SR, j, goff);
-        }
-        const float* da_p = strip + poff + ca * C::PS;
-        const float* db_p = strip + poff + cb * C::PS;
-        f32x4 acc[C::NS][4];
-#pragma unroll
-        for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s][r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // Left to the compiler's own schedule: it splits a point in one VALU burst and then issues that point's twelve MFMAs back
-        // to back.  Forcing the interleave (software pipeline over the 8 (block, point) steps + sched_group_barrier "1 MFMA, 2 or 4
-        // VALU") was measured SLOWER on the MI355X -- 38.6 (pipelined, unpinned), 41.2 (2 VALU per MFMA), 42.3 (4) against 37.1 ms per
-        // 1 M cells for this form -- as were unpacked adds (inline v_sub_f32 instead of the v_pk_add_f32 the compiler pairs them into).
-#pragma unroll
-        for (int kb = 0; kb < W3X::NKB; ++kb) {
-            // V[:, c] of the lane's 8 channels: halves h = channels 32 kb + 16 h + 4 kq .. +3
-            f32x4 v[4][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 da = *(const f32x4*)(da_p + i * W3X::ROWP + 32 * kb + 16 * h);
-                    const f32x4 db = *(const f32x4*)(db_p + i * W3X::ROWP + 32 * kb + 16 * h);
-                    w[i] = da + sg * db;
-                }
-                v[0][h] = w[0] - w[2]; v[1][h] = w[1] + w[2]; v[2][h] = w[2] - w[1]; v[3][h] = w[1] - w[3];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bf16x8 a1, a2, a3;
-                w3x_split8(v[r][0], v[r][1], a1, a2, a3);
-#pragma unroll
-                for (int s = 0; s < C::NS; ++s) {
-                    f32x4 d = acc[s][r];
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[r][s][kb][2], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[r][s][kb][1], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, B[r][s][kb][0], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[r][s][kb][1], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, B[r][s][kb][0], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, B[r][s][kb][0], d, 0, 0, 0);
-                    acc[s][r] = d;
-                }
-            }
-        }
-        // row fold s = A^T M of each slice, left in LDS for the column fold
-#pragma unroll
-        for (int s = 0; s < C::NS; ++s) {
-            f32x4 s0, s1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s0[r] = (acc[s][0][r] + acc[s][1][r]) + acc[s][2][r];
-                s1[r] = (acc[s][1][r] - acc[s][2][r]) - acc[s][3][r];
-            }
-            float* x = xch + ((size_t)((wc * C::NS + s) * 2) * 64 + lane) * 4;
-            *(f32x4*)x = s0;
-            *(f32x4*)(x + 64 * 4) = s1;
-        }
-        if (has_next) {
-#pragma unroll
-            for (int j = 0; j < C::NLD; ++j) st_store(nstrip, (int)(nitem % C::NGRP) * C::SR, j, stg[j]);
-        }
-        __syncthreads();   // s of all four columns in LDS; this strip fully read; next strip complete
-        f32x4 t0[4], t1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float* x = xch + ((size_t)((c * C::NS + fs) * 2) * 64 + lane) * 4;
-            t0[c] = *(const f32x4*)x;
-            t1[c] = *(const f32x4*)(x + 64 * 4);
-        }
-        const f32x4 y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-        const f32x4 y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
-        auto post = [&](float v) { v += bias; v = fmaxf(v, 0.0f); return fmaf(v, bns, bnt); };
-#pragma unroll
-        for (int rr = 0; rr < C::FR; ++rr) {
-            const float a = rbase ? y00[2 + rr] : y00[rr], b = rbase ? y01[2 + rr] : y01[rr];
-            const float c2 = rbase ? y10[2 + rr] : y10[rr], d = rbase ? y11[2 + rr] : y11[rr];
-            const float mx = fmaxf(fmaxf(a, b), fmaxf(c2, d)), mn = fminf(fminf(a, b), fminf(c2, d));
-            const float res = post(bns >= 0.0f ? mx : mn);
-            const int t = 4 * kq + rbase + rr;
-            const int ty = grp * C::TR + t / C::TW, tx = t % C::TW;
-            out[(((size_t)cell * (C::H / 2) + ty) * (C::W / 2) + tx) * C::COUT + co] = res;
-        }
-        __syncthreads();   // exchange area free again
-        buf ^= 1;
-    }
-}
-
 // ---- conv3 with the Winograd-domain contraction as a TWO-term fp16 split (three products) ---------------------------------
 // conv_wino_up.hip (conv67_h2_kernel) has the algebra and the hardware facts; tests/study_split_fp16.py measures conv3 in this form
-// at 2.6e-7 of the feature range (the fp32 MFMA chain: 5.2e-7).  The decomposition is conv3_wino_x3_kernel's, with half the matrix
-// instructions (768 per cell), a 3-instruction split per transformed value instead of 5.5, and U as two fp16 planes in 128 VGPRs --
-// which lets TWO workgroups share a CU (two waves per SIMD: one workgroup's barriers and split bursts under the other's MFMAs),
-// where the bf16 form's 192 weight registers allowed one.
+// at 2.6e-7 of the feature range (the fp32 MFMA chain: 5.2e-7).  768 matrix
+// instructions per cell, a 3-instruction split per transformed value, and U as two fp16 planes in 128 VGPRs -- which lets TWO
+// workgroups share a CU (two waves per SIMD: one workgroup's barriers and split bursts under the other's MFMAs).
 //   scale   |V| <= 4 max|p2| (B^T of F(2,3) has absolute row sums 2): S puts 4 max|p2| of the STRIP into [2^14, 2^15); the
 //           maximum is taken where the next strip is staged (registers -> DPP row max -> LDS atomic max, read behind the
 //           barrier that is there anyway).  The strip itself stays fp32 in LDS (the transform runs in fp32); V S is split in
@@ -909,73 +729,9 @@ size_t pack_wino_cs_fragments(int layer, const float* hwio, float* dst)
     return layer == 1 ? pack_frags<WinoL2>(hwio, dst) : pack_frags<WinoL3>(hwio, dst);
 }
 
-// conv3's U = G g G^T (double, rounded once to fp32) as three bf16 planes in conv3_wino_x3_kernel's order:
-// [wave c][r][slice][channel block][plane][lane][8]: element j of lane (li, kq) = plane of U[4 r + c][ci][16 slice + li] with
-// ci = 32 block + (j < 4 ? 4 kq + j : 16 + 4 kq + j - 4)
-size_t pack_wino3_x3(const float* hwio /* [3][3][64][32] */, uint16_t* dst)
-{
-    using C = WinoL3;
-    const size_t total = (size_t)4 * 4 * C::NS * W3X::NKB * 3 * 64 * 8;
-    if (!dst) return total;
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    auto rne = [](float x) -> uint16_t {
-        uint32_t u;
-        memcpy(&u, &x, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    };
-    auto val = [](uint16_t h) -> float {
-        const uint32_t u = (uint32_t)h << 16;
-        float x;
-        memcpy(&x, &u, 4);
-        return x;
-    };
-    for (int c = 0; c < 4; ++c)
-        for (int r = 0; r < 4; ++r)
-            for (int s = 0; s < C::NS; ++s)
-                for (int kb = 0; kb < W3X::NKB; ++kb)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int li = lane & 15, kq = lane >> 4, co = 16 * s + li;
-                            const int ci = 32 * kb + (j < 4 ? 4 * kq + j : 16 + 4 * kq + j - 4);
-                            double u = 0.0;
-                            for (int a = 0; a < 3; ++a)
-                                for (int b = 0; b < 3; ++b)
-                                    u += G[r][a] * (double)hwio[((size_t)(a * 3 + b) * C::CIN + ci) * C::COUT + co] * G[c][b];
-                            const float v = (float)u;
-                            const uint16_t w1 = rne(v);
-                            const float r1 = v - val(w1);
-                            const uint16_t w2 = rne(r1);
-                            const uint16_t pl[3] = {w1, w2, rne(r1 - val(w2))};
-                            for (int p = 0; p < 3; ++p)
-                                dst[((((((size_t)c * 4 + r) * C::NS + s) * W3X::NKB + kb) * 3 + p) * 64 + lane) * 8 + j] = pl[p];
-                        }
-    return total;
-}
-
-hipError_t launch_conv3_wino_x3(const float* in, const uint16_t* uplanes, const float* ep, float* out, int64_t n_cells, hipStream_t stream)
-{
-    static int resident = 0;
-    if (!resident) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3_wino_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3X::LDS);
-        if (e != hipSuccess) return e;
-        int dev = 0, cus = 0, per_cu = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv3_wino_x3_kernel, 256, W3X::LDS)) != hipSuccess) return e;
-        if (per_cu < 1) per_cu = 1;
-        resident = cus * per_cu;
-    }
-    const long total = (long)n_cells * WinoL3::NGRP;
-    if (total <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)(total < resident ? total : resident);
-    hipLaunchKernelGGL(conv3_wino_x3_kernel, dim3(grid), dim3(256), W3X::LDS, stream, in, (const bf16x8*)uplanes, ep, out, (long)n_cells);
-    return hipGetLastError();
-}
-
 // conv3's U = G g G^T (double, rounded once to fp32) as two fp16 planes of S_w U in conv3_wino_h2_kernel's order:
-// [wave c][r][slice][channel block][plane 2][lane][8], the element order of pack_wino3_x3; *inv_sw = 1 / S_w
+// [wave c][r][slice][channel block][plane 2][lane][8]: element j of lane (li, kq) = plane of U[4 r + c][ci][16 slice + li] with
+// ci = 32 block + (j < 4 ? 4 kq + j : 16 + 4 kq + j - 4); *inv_sw = 1 / S_w
 size_t pack_wino3_h2(const float* hwio /* [3][3][64][32] */, uint16_t* dst, float* inv_sw)
 {
     using C = WinoL3;
@@ -1034,7 +790,7 @@ hipError_t launch_conv3_wino_h2(const float* in, const uint16_t* uplanes, float 
 hipError_t launch_conv_wino_cs(int layer, const float* in, const float* ufrag, const float* ep, float* out, int64_t n_cells,
                                hipStream_t stream)
 {
-    static const bool no_ring = getenv("CS_WINO_NO_RING") != nullptr || getenv("CS_WINO_DIAG") != nullptr;
+    static const bool no_ring = getenv("CS_WINO_DIAG") != nullptr;       // tools/wino_diag.py stamps the strip kernel
     if (layer == 1 && !no_ring) {
         static int resident = 0;
         constexpr int lds = 2 * WinoL2::STRIP + WinoL2::XCH;

@@ -483,276 +483,25 @@ __global__ __launch_bounds__(WUL6::THREADS, 1) void conv67_fused_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same fused kernel with conv6's contraction on the bf16 matrix pipe (conv45_bf16x3.hip has the algebra: every fp32
-// operand as three bf16 terms, a product as six v_mfma_f32_16x16x32_bf16; in the fp32 error class, measured).  conv6 runs
-// in its FOLDED-DIRECT form here -- four 2x2-tap phase convs over the stored grid, 16/9 of the Winograd form's multiply-adds --
-// because a Winograd input transform would have to be split again for every transformed value (5.5 VALU instructions each,
-// more than the MFMAs they feed at 32 filters), whereas the stored pixels are split ONCE when the strip is staged.
-// 6,144 bf16 MFMAs per cell at 16 cycles replace 4,608 fp32 MFMAs at 32 plus the transforms' VALU work, and the bf16
-// instruction leaves half of its issue slots to the other wave's VALU / LDS instructions.
-//   strip: the group's 4 stored rows + halo as [row 6][pixel 18][x1: 64 ch | x2 | x3 | 32 B] bf16 -- 416 B per pixel = twice
-//          an odd number of 16-byte slots, so every ds_read_b128 lane group lands on 16 distinct slots; single-buffered: the
-//          next strip is written between the two barriers of a group, when no wave reads the current one any more;
-//   wave = (phase, 16-filter half): B = 4 taps x 2 channel blocks x 3 planes x 4 VGPRs = 96 registers; a tile is one stored
-//          row of the group (16 pixels), its A fragment of one (tap, block) three ds_read_b128 at immediate offsets;
+// The same fused kernel with conv6's contraction on the 16-bit matrix pipe.  conv6 runs in its FOLDED-DIRECT form here -- four
+// 2x2-tap phase convs over the stored grid, 16/9 of the Winograd form's multiply-adds -- because a Winograd input transform
+// would have to be split again for every transformed value (more VALU instructions than the MFMAs they feed at 32 filters),
+// whereas the stored pixels are split ONCE when the strip is staged.
+//   strip: the group's 4 stored rows + halo as [row 6][pixel 18][hi: 64 ch | lo | 32 B] fp16 -- twice an odd number of 16-byte
+//          slots per pixel, so every ds_read_b128 lane group lands on 16 distinct slots; single-buffered: the next strip is
+//          written between the two barriers of a group, when no wave reads the current one any more;
+//   wave = (phase, 16-filter half): B = 4 taps x 2 channel blocks x 2 planes x 4 VGPRs = 64 registers; a tile is one stored
+//          row of the group (16 pixels), its A fragment of one (tap, block) two ds_read_b128 at immediate offsets;
 //   everything after the a6 block (T = a6 W_eff^T on fp32 MFMAs, the T ring, gather, sigmoid, error sums) is the code above.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-struct F67X {
-    static constexpr int PXB = 6 * 64 + 32;                    // bytes per staged pixel
-    static constexpr int PLB = 2 * 64;                         // byte offset of a plane inside the pixel
-    static constexpr int ROWB = 18 * PXB;
-    static constexpr int STRIP = 6 * ROWB;                     // 44,928 B
-    // T ring, n-major: [ring row 16][n 16][x 34 -> 36].  The gather's 32 lanes of a ds_read_b32 are 16 columns x 2 column phases;
-    // with the (x, n) order of the fp32 kernel a phase step is 64 B + 16 B and the 32 lanes fall on 4 banks (8-way, a third of
-    // this kernel's LDS cycles); here a phase step is 4 rows + 1 float = 145 floats = 17 banks: 31 distinct banks
+// T ring, n-major: [ring row 16][n 16][x 34 -> 36].  The gather's 32 lanes of a ds_read_b32 are 16 columns x 2 column phases;
+// with the (x, n) order of the fp32 kernel a phase step is 64 B + 16 B and the 32 lanes fall on 4 banks (8-way); here a
+// phase step is 4 rows + 1 float = 145 floats = 17 banks: 31 distinct banks
+struct F67T {
     static constexpr int TW = 36;
     static constexpr int T_BYTES = F67::TSLOTS * 16 * TW * 4;  // 36,864 B
-    static constexpr int LDS = STRIP + F67::A6_BYTES + T_BYTES + F67::W_BYTES;
-    static_assert(LDS <= 160 * 1024 && STRIP % 16 == 0, "LDS budget");
 };
 
-__device__ __forceinline__ void x3_split4(const f32x4& v, bf16x4& h1, bf16x4& h2, bf16x4& h3)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 a1 = (__bf16)v[j];
-        const float r1 = v[j] - (float)a1;
-        const __bf16 a2 = (__bf16)r1;
-        const float r2 = r1 - (float)a2;
-        h1[j] = a1;
-        h2[j] = a2;
-        h3[j] = (__bf16)r2;
-    }
-}
-
-// pass j of the row-wise staging (rows rsub + 2 j of the 6-row strip whose first stored row is y0 - 1): split and store
-__device__ __forceinline__ void x3_store(char* strip, int y0, int j, int rsub, int loffb, f32x4 v)
-{
-    const int r = rsub + WUL6::RPP * j;
-    const int sy = y0 - 1 + r;
-    if (sy < 0 || sy >= WUL6::HS) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // halo rows of the image
-    bf16x4 h1, h2, h3;
-    x3_split4(v, h1, h2, h3);
-    char* d = strip + r * F67X::ROWB + loffb;
-    *(bf16x4*)d = h1;
-    *(bf16x4*)(d + F67X::PLB) = h2;
-    *(bf16x4*)(d + 2 * F67X::PLB) = h3;
-}
-
-// DIAG stamps as conv67_fused_kernel's: [0] load issue, [1] MFMAs, [2] a6 block to LDS + barrier, [3] T + next strip to LDS +
-// barrier, [4] gather, sigmoid, error terms.
-template <bool DIAG>
-__global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_x3_kernel(
-    const float* __restrict__ in /* a5 */, const bf16x8* __restrict__ wfrag, const float* __restrict__ ep /* [3][32] */,
-    const float* __restrict__ x /* crops [n][64][64] */, const float* __restrict__ weff /* [16][32] */,
-    const float* __restrict__ b7p, float* __restrict__ errpart /* [n][8][2] */, long n_cells,
-    unsigned long long* __restrict__ diag)
-{
-    using C = WUL6;
-    static_assert(C::NLD == 3 && C::RPP == 2 && C::R == 6 && C::EPR == 256, "row-wise staging constants");
-    unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt = 0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* a6s = (float*)(smem + F67X::STRIP);
-    float* tb = (float*)(smem + F67X::STRIP + F67::A6_BYTES);
-    float* wl = (float*)(smem + F67X::STRIP + F67::A6_BYTES + F67X::T_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = wave >> 1, wsl = wave & 1;
-    const int pa = ph >> 1, pb = ph & 1;
-    const int li = lane & 15, kq = lane >> 4;
-
-    bf16x8 B[4][2][3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) B[t][k][p] = wfrag[(((wave * 4 + t) * 2 + k) * 3 + p) * 64 + lane];
-    const int co = wsl * 16 + li;
-    const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
-    const float b7 = b7p[0];
-
-    const long first = blockIdx.x;
-    if (first >= n_cells) return;
-    const int se = tid & (C::EPR - 1), rsub = tid / C::EPR;
-    const int spx = se / C::C4, sc4 = se & (C::C4 - 1);
-    const int goff = spx * C::CIN + sc4 * 4;
-    const int loffb = (spx + 1) * F67X::PXB + sc4 * 8;             // +1: halo column (zeroed once, never rewritten)
-    auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::HS * C::WS * C::CIN; };
-    for (int i = tid; i < F67X::LDS / 16; i += C::THREADS) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    __syncthreads();
-    wl[(tid >> 5) * 36 + (tid & 31)] = weff[tid];                  // [n][c], 512 floats, padded rows
-#pragma unroll
-    for (int j = 0; j < C::NLD; ++j) x3_store(smem, 0, j, rsub, loffb, wu_load<C>(cell_ptr(first), 0, j, rsub, goff));
-    __syncthreads();
-    // A operand: stored (t + a - 1 + ry, xs + b - 1 + rx) of the group = staged (t + a + ry, xs + b + rx); lane = (xs, 8 channels at 8 kq)
-    const char* abase = smem + (pa * 18 + li + pb) * F67X::PXB + kq * 16;
-
-    for (long cell = first; cell < n_cells; cell += gridDim.x) {
-        const float* xc = x + (size_t)cell * 64 * 64;
-        float s2 = 0.0f, s1 = 0.0f;
-#pragma unroll 1
-        for (int grp = 0; grp < C::NGRP; ++grp) {
-            const long ncell = grp < C::NGRP - 1 ? cell : cell + gridDim.x;
-            const int ngrp = grp < C::NGRP - 1 ? grp + 1 : 0;
-            const bool has_next = ncell < n_cells;
-
-            if constexpr (DIAG) dt = wu_stamp();
-            f32x4 stg[C::NLD];
-            if (has_next) {
-#pragma unroll
-                for (int j = 0; j < C::NLD; ++j) stg[j] = wu_load<C>(cell_ptr(ncell), ngrp * C::SR, j, rsub, goff);
-            }
-            // the crop pixels this thread's outputs are compared with (unconditional, clamped loads)
-            float xv[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = wave + 8 * h, o = 2 * (8 * grp + (k >> 1)) - 1 + (k & 1);
-                xv[h] = xc[(o < 0 ? 0 : o) * 64 + lane];
-            }
-            float xtail = 0.0f;
-            if (grp == C::NGRP - 1 && wave == 0) xtail = xc[63 * 64 + lane];
-
-            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[0] += t - dt; dt = t; }
-            // ---- conv6, folded direct, six bf16 products per (tile, tap, 32-channel block)
-            f32x4 acc[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            // walked by STAGED fragment, not by tile: the fragment at staged row sr (column shift rx, block k) is tap (0, rx) of
-            // tile sr and tap (1, rx) of tile sr - 1 -- 60 plane reads per group instead of 96, each consumed by the 6 or 12
-            // MFMAs that follow it; the next fragment's reads are issued ahead of them and pinned there
-            auto rd = [&](int f, bf16x8 (&a)[3]) {
-                const int sr = f >> 2, rx = (f >> 1) & 1, k = f & 1;
-                const char* p = abase + sr * F67X::ROWB + rx * F67X::PXB + k * 64;
-                a[0] = *(const bf16x8*)p;
-                a[1] = *(const bf16x8*)(p + F67X::PLB);
-                a[2] = *(const bf16x8*)(p + 2 * F67X::PLB);
-            };
-            auto mac6 = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& d) {
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], d, 0, 0, 0);
-            };
-            {
-                bf16x8 a[3];
-                rd(0, a);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-                for (int f = 0; f < 20; ++f) {
-                    const int sr = f >> 2, rx = (f >> 1) & 1, k = f & 1;
-                    bf16x8 an[3] = {a[0], a[1], a[2]};
-                    if (f + 1 < 20) rd(f + 1, an);
-                    if (sr < 4) mac6(a, B[rx][k], acc[sr]);
-                    if (sr > 0) mac6(a, B[2 + rx][k], acc[sr - 1]);
-                    a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    if (sr > 0 && sr < 4) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                }
-            }
-            if constexpr (DIAG) {
-                asm volatile("" ::"v"(acc[0][0]), "v"(acc[3][3]));
-                const unsigned long long t = wu_stamp(); dg[1] += t - dt; dt = t;
-            }
-            // ---- bias -> relu -> BN; D row 4 kq + r = stored pixel xs of stored row t -> a6 block row 2 t + a, column 2 xs + b
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(acc[t][r] + bias, 0.0f);
-                    a6s[((2 * t + pa) * 32 + 2 * (4 * kq + r) + pb) * F67::PA + co] = fmaf(v, bns, bnt);
-                }
-            __syncthreads();
-            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[2] += t - dt; dt = t; }
-            // ---- T = a6 W_eff^T for local row `wave`, 16 pixels per MFMA chain; K order: channel 8 kq + s
-            float wc[8];                                                                 // W_eff[n = li][c = 8 kq + s]
-            *(f32x4*)&wc[0] = *(const f32x4*)(wl + li * 36 + kq * 8);
-            *(f32x4*)&wc[4] = *(const f32x4*)(wl + li * 36 + kq * 8 + 4);
-            {
-                const float* ap = a6s + ((wave * 32 + li) * F67::PA + kq * 8);
-                const f32x4 a00 = *(const f32x4*)ap, a01 = *(const f32x4*)(ap + 4);
-                const f32x4 a10 = *(const f32x4*)(ap + 16 * F67::PA), a11 = *(const f32x4*)(ap + 16 * F67::PA + 4);
-                f32x4 t0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;                     // two independent chains, interleaved
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[s], wc[s], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[s], wc[s], t1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
-                }
-                // T[ring row][n = li][x + 1]: n-major rows (see F67X)
-                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67X::TW + 4 * kq + 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { tw[r] = t0[r]; tw[16 + r] = t1[r]; }
-            }
-            if (has_next) {      // every wave is past the first barrier: nobody reads the current strip any more
-#pragma unroll
-                for (int j = 0; j < C::NLD; ++j) x3_store(smem, ngrp * C::SR, j, rsub, loffb, stg[j]);
-            }
-            __syncthreads();
-            if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
-            // ---- gather: new a6 row y finishes output rows 2y - 1 (phase a = 1 of row y - 1) and 2y (a = 0)
-            const int px = lane & 1, xh = (lane >> 1) + px;                              // halo column of rx = 0
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = wave + 8 * h;                                              // wave-uniform
-                const int y = 8 * grp + (k >> 1), e = k & 1;
-                if (2 * y - 1 + e < 0) continue;
-                const int nb = ((1 - e) * 2 + px) * 4;
-                const float* ra = tb + ((((y - 1) & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
-                const float* rb = tb + (((y & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
-                float ta0 = ra[0], ta1 = ra[F67X::TW + 1];
-                const float tb0 = rb[2 * F67X::TW], tb1 = rb[3 * F67X::TW + 1];
-                if (y == 0) { ta0 = 0.0f; ta1 = 0.0f; }                                  // row -1: zero padding
-                const float v = ((ta0 + ta1) + (tb0 + tb1)) + b7;
-                const float rr = f67_sigmoid(v);
-                const float d = xv[h] - rr;
-                s2 = fmaf(d, d, s2);
-                s1 += fabsf(d);
-            }
-            if (grp == C::NGRP - 1 && wave == 0) {                                      // output row 63: a6 row 31 and the padding
-                const int nb = (2 + px) * 4;
-                const float* ra = tb + (((31 & (F67::TSLOTS - 1)) * 16) + nb) * F67X::TW + xh;
-                const float v = (ra[0] + ra[F67X::TW + 1]) + b7;
-                const float rr = f67_sigmoid(v);
-                const float d = xtail - rr;
-                s2 = fmaf(d, d, s2);
-                s1 += fabsf(d);
-            }
-            if constexpr (DIAG) {
-                asm volatile("" ::"v"(s2), "v"(s1));
-                const unsigned long long t = wu_stamp(); dg[4] += t - dt; dt = t;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s2 += __shfl_down(s2, off, 64);
-            s1 += __shfl_down(s1, off, 64);
-        }
-        if (lane == 0) {
-            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 0] = s2;
-            errpart[((size_t)cell * F67::NPARTS + wave) * 2 + 1] = s1;
-        }
-    }
-    if constexpr (DIAG) {
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) diag[((size_t)blockIdx.x * 8 + wave) * 5 + k] = dg[k];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The same kernel with conv6's contraction as a TWO-term fp16 split (three products) instead of the three-term bf16 split
-// (six): fp16 carries 11 significant bits, so x = hi + lo (hi = fp16(x), lo = fp16(x - hi)) holds 22, and
+// The arithmetic: a TWO-term fp16 split (three products).  fp16 carries 11 significant bits, so x = hi + lo (hi = fp16(x), lo = fp16(x - hi)) holds 22, and
 //     x w ~ hi_x hi_w + (hi_x lo_w + lo_x hi_w)
 // with every partial product exact in the MFMA's fp32 accumulator (v_mfma_f32_16x16x32_f16, the bf16 instruction's rate): HALF
 // the matrix instructions, two thirds of the weight registers and LDS bytes, a 3-instruction split per value instead of 5.5.
@@ -775,8 +524,8 @@ struct F67H {
     static constexpr int PXB = 2 * PLB + 32;                   // 288 B per staged pixel = twice an odd number of 16-byte slots
     static constexpr int ROWB = 18 * PXB;
     static constexpr int STRIP = 6 * ROWB;                     // 31,104 B
-    static constexpr int TW = F67X::TW;
-    static constexpr int T_BYTES = F67X::T_BYTES;
+    static constexpr int TW = F67T::TW;
+    static constexpr int T_BYTES = F67T::T_BYTES;
     static constexpr int OFF_MAX = STRIP + F67::A6_BYTES + T_BYTES + F67::W_BYTES;   // two words: the strip maxima (alternating)
     static constexpr int LDS = OFF_MAX + 16;
     static_assert(LDS <= 160 * 1024 && STRIP % 16 == 0, "LDS budget");
@@ -1107,7 +856,7 @@ hipError_t launch(int layer, const float* in, const float* ufrag, const float* e
 {
     static int resident = 0;
     static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
-    static const int LDSB = getenv("CS_WU_LDS") ? atoi(getenv("CS_WU_LDS")) : C::LDS;   // experiment: more LDS = fewer workgroups per CU
+    constexpr int LDSB = C::LDS;
     if (!resident) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_wino_up_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         if (e != hipSuccess) return e;
@@ -1170,72 +919,7 @@ hipError_t launch_conv67_fused(const float* a5, const float* ufrag, const float*
     return hipGetLastError();
 }
 
-// conv6's folded weights (pack_generic_folded(64, 32, ...): [phase 4][tap 4][cin 64][cout 32]) as bf16 planes in conv67_x3_kernel's
-// order: [wave = phase * 2 + half][tap][block 2][plane 3][lane 64][8]: element j = plane of W_eff[phase][tap][32 block + 8 kq + j][16 half + li]
-size_t pack_conv6_bf16x3(const float* weff, uint16_t* dst)
-{
-    const size_t n = (size_t)8 * 4 * 2 * 3 * 64 * 8;
-    if (!dst) return n;
-    auto rne = [](float x) -> uint16_t {
-        uint32_t u;
-        memcpy(&u, &x, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    };
-    auto val = [](uint16_t h) -> float {
-        const uint32_t u = (uint32_t)h << 16;
-        float x;
-        memcpy(&x, &u, 4);
-        return x;
-    };
-    for (int w = 0; w < 8; ++w)
-        for (int t = 0; t < 4; ++t)
-            for (int k = 0; k < 2; ++k)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int ph = w >> 1, half = w & 1, li = l & 15, kq = l >> 4;
-                        const float v = weff[((size_t)(ph * 4 + t) * 64 + 32 * k + 8 * kq + j) * 32 + 16 * half + li];
-                        const uint16_t w1 = rne(v);
-                        const float r1 = v - val(w1);
-                        const uint16_t w2 = rne(r1);
-                        const float r2 = r1 - val(w2);
-                        const uint16_t pl[3] = {w1, w2, rne(r2)};
-                        for (int p = 0; p < 3; ++p) dst[((((((size_t)w * 4 + t) * 2 + k) * 3 + p) * 64) + l) * 8 + j] = pl[p];
-                    }
-    return n;
-}
-
-hipError_t launch_conv67_x3(const float* a5, const uint16_t* wplanes, const float* ep, const float* x, const float* weff_dev,
-                            const float* b7_dev, float* errpart, int64_t n_cells, hipStream_t stream)
-{
-    static int cus = 0;
-    static const bool diag = getenv("CS_WINO_DIAG") != nullptr;
-    if (!cus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv67_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F67X::LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv67_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F67X::LDS);
-        if (e != hipSuccess) return e;
-        int dev = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if (diag && !g_wu_diag[3]) {                               // slot 3 of the diagnostic table: the fused kernel (either form)
-            if ((e = hipMalloc(&g_wu_diag[3], (size_t)cus * 40 * sizeof(unsigned long long))) != hipSuccess) return e;
-            g_wu_diag_blocks[3] = cus;
-        }
-    }
-    if (n_cells <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)(n_cells < cus ? n_cells : cus);
-    if (diag)
-        hipLaunchKernelGGL(conv67_x3_kernel<true>, dim3(grid), dim3(WUL6::THREADS), F67X::LDS, stream, a5, (const bf16x8*)wplanes, ep, x,
-                           weff_dev, b7_dev, errpart, (long)n_cells, g_wu_diag[3]);
-    else
-        hipLaunchKernelGGL(conv67_x3_kernel<false>, dim3(grid), dim3(WUL6::THREADS), F67X::LDS, stream, a5, (const bf16x8*)wplanes, ep, x,
-                           weff_dev, b7_dev, errpart, (long)n_cells, (unsigned long long*)nullptr);
-    return hipGetLastError();
-}
-
-// The power of two that puts max|w| into [2^14, 2^15) (1 for an all-zero array), for the fp16 split of a weight array.
+// helpers of every fp16-split packer: the power of two that puts max|w| into [2^14, 2^15), and one value's two fp16 terms
 float f16x2_weight_scale(const float* w, size_t n)
 {
     float m = 0.0f;

@@ -479,6 +479,10 @@ __global__ void finalize_kernel(const float* __restrict__ errpart, int nparts, i
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // A crop with a NaN / Inf pixel: its error sums are NaN / Inf (what NumPy's mean((X - R)**2) gives, improved_detection.py:126-127);
+    // its scores are reported as NaN and both flags as -1 (the reference raises in pca.transform: "Input X contains NaN").  The
+    // convs saw that pixel as 0 (conv12_fused.hip), so no other cell is touched.
+    bool bad = false;
     if (errpart) {
         float s2 = 0.0f, s1 = 0.0f;
         for (int p = 0; p < nparts; ++p) {
@@ -487,14 +491,16 @@ __global__ void finalize_kernel(const float* __restrict__ errpart, int nparts, i
         }
         if (mse) mse[i] = s2 / (float)npix;
         if (mae) mae[i] = s1 / (float)npix;
+        bad = !(fabsf(s2) <= 3.402823466e38f && fabsf(s1) <= 3.402823466e38f);
     }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
     if (dec_c) {
-        const double d = dec_c[i];
+        const double d = bad ? qnan : dec_c[i];
         if (score_c) score_c[i] = -d;                 // improved_detection.py:149
         if (pred_c) pred_c[i] = (d > 0) ? 1 : -1;     // svm.cpp:2838
     }
     if (dec_m) {
-        const double d = dec_m[i];
+        const double d = bad ? qnan : dec_m[i];
         if (score_m) score_m[i] = -d;
         if (pred_m) pred_m[i] = (d > 0) ? 1 : -1;
     }

@@ -26,9 +26,17 @@ static int repack(cs_trainer* t)
     return CS_OK;
 }
 
+constexpr int kTrainMaxBatch = 8192;
+static_assert((long)kTrainMaxBatch * 4 <= (long)BN_MAX_PARTS * 64, "conv7's loss epilogue leaves 4 partials per cell in dzsum_part[6]");
+static_assert((long)kTrainMaxBatch * 64 * 64 * 32 < (1L << 31), "the BatchNormalization kernels index below 2^31");
+
 static int ensure_batch(cs_trainer* t, int64_t b)
 {
     if (b <= t->maxb) return CS_OK;
+    // conv7's loss epilogue leaves 4 bias-gradient partials per cell in dzsum_part[6] (BN_MAX_PARTS * 64 floats), and the
+    // BatchNormalization kernels index the 32x64x64 tensors below 2^31: both hold up to this batch
+    if (b > kTrainMaxBatch)
+        return fail(CS_ERR_UNSUPPORTED, "a batch of %lld cells exceeds the trainer's limit of %d (the reference trains on 32)", (long long)b, kTrainMaxBatch);
     int rc;
     if ((rc = t->x.ensure((size_t)b * kH * kW * 4)) || (rc = t->y.ensure((size_t)b * kH * kW * 4))) return rc;
     for (int l = 0; l < 6; ++l) {

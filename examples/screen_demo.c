@@ -33,7 +33,7 @@ int main(int argc, char **argv)
         return 3;
     }
     cs_model *m = NULL;
-    int rc = cs_model_load(argv[1], 0, &m);
+    int rc = cs_model_load(argv[1], 0, NULL /* default options: CS_PRECISION_SPLIT16 */, &m);
     if (rc) return die("cs_model_load", rc);
     cs_model_info info;
     if ((rc = cs_model_get_info(m, &info))) return die("cs_model_get_info", rc);

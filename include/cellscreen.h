@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2       /* 2: cs_model_options (precision) on cs_model_load / cs_model_from_arrays */
 #define CS_MAX_CONV 16
 
 typedef enum cs_status {
@@ -126,6 +126,32 @@ typedef struct cs_detector_params {
     cs_ocsvm_params moderate;         /* nu = 0.10 */
 } cs_detector_params;
 
+/* How the fp32 contractions of the convs and of the PCA projection are evaluated.  Either way every tensor, bias,
+ * BatchNormalization constant, accumulator and result is fp32 (the SVMs fp64), as in the reference
+ * (improved_detection.py:122,125,130: Keras's float32 predict).
+ *   CS_PRECISION_SPLIT16     (default) each fp32 operand as a two-term fp16 split (22 of 24 mantissa bits; exact
+ *                            power-of-two scales per cell / strip) contracted by three products on the 16-bit
+ *                            matrix instructions with fp32 accumulation; the PCA GEMM as a three-term bf16 split
+ *                            (24 bits).  Inside every fp32 tolerance of tests/helpers.py; DESIGN.md section 3h.
+ *   CS_PRECISION_FP32_EXACT  every contraction on v_mfma_f32_16x16x4_f32: fp32 operands, fp32 products, fp32
+ *                            accumulation -- the reference's own arithmetic up to summation order.  ~0.58x the rate. */
+typedef enum cs_precision { CS_PRECISION_SPLIT16 = 0, CS_PRECISION_FP32_EXACT = 1 } cs_precision;
+
+/* Debug-only switches (A/B runs and the bit-identity tests): each keeps an UNFUSED form of the same arithmetic. */
+#define CS_DEBUG_NO_FUSE12      0x1u   /* conv1 and conv2 as two kernels, p1 through HBM (conv2 as F(2x2,3x3): other bits) */
+#define CS_DEBUG_NO_FUSE45      0x2u   /* conv4 and conv5 as two kernels, a4 through HBM (bit-identical) */
+#define CS_DEBUG_NO_FUSE67      0x4u   /* conv6, conv7 + error as two kernels, a6 through HBM */
+#define CS_DEBUG_NO_SMALL_SPLIT 0x8u   /* small calls keep the one-workgroup detector tail (bit-identical) */
+
+/* Options of cs_model_load / cs_model_from_arrays; NULL = all defaults.  Set struct_size = sizeof(cs_model_options)
+ * and zero the rest before filling in what is wanted. */
+typedef struct cs_model_options {
+    uint32_t struct_size;
+    int32_t precision;                /* cs_precision */
+    uint32_t debug_flags;             /* CS_DEBUG_* ; 0 in production */
+    uint32_t reserved[5];             /* must be 0 */
+} cs_model_options;
+
 typedef struct cs_model_info {
     int32_t height, width;
     int32_t n_conv, n_enc;
@@ -139,6 +165,8 @@ typedef struct cs_model_info {
     int64_t chunk_cells;              /* cells processed per internal pass */
     int32_t channels[CS_MAX_CONV];    /* filters of each conv */
     int32_t reference_arch;           /* 1: the reference graph (tuned kernels); 0: generic-shape kernels */
+    int32_t precision;                /* cs_precision the handle was created with */
+    uint32_t debug_flags;
 } cs_model_info;
 
 /* ---- library / device ---------------------------------------------------------- */
@@ -152,7 +180,7 @@ int cs_device_count(void);
 /* Reads <model_dir>/cae.bin (+ detector.bin if present) in the native tensor-archive
  * format written by cellscreen.model_io (see DESIGN.md "model_dir").
  * Replaces load_trained_models, improved_detection.py:23-46. */
-int cs_model_load(const char *model_dir, int device_id, cs_model **out);
+int cs_model_load(const char *model_dir, int device_id, const cs_model_options *options, cs_model **out);
 
 /* autoencoder: weights of best_autoencoder.keras (improved_detection.py:28).
  * encoder:     weights of encoder.keras (:29), n_conv = n_enc convs; NULL = same as the
@@ -167,7 +195,8 @@ int cs_model_load(const char *model_dir, int device_id, cs_model **out);
  * channel counts multiples of 4.  Anything else: CS_ERR_UNSUPPORTED.  Training handles (cs_train_*) take
  * the same architectures (cs_train_create). */
 int cs_model_from_arrays(const cs_cae_weights *autoencoder, const cs_cae_weights *encoder,
-                         const cs_detector_params *detector, int device_id, cs_model **out);
+                         const cs_detector_params *detector, int device_id, const cs_model_options *options,
+                         cs_model **out);
 void cs_model_free(cs_model *m);
 /* Orders the handle's stream after all work enqueued so far on `hip_stream` (a hipStream_t; NULL = the legacy
  * default stream).  See "Device INPUTS" above.  Same for the three other handle types. */

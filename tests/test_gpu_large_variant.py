@@ -96,45 +96,39 @@ def test_rectangular_variant_with_odd_channel_counts():
 
 
 @pytest.mark.parametrize("scale", [1.0, 255.0, 1.0e-3])
-def test_generic_fp16_split_convs_scale_with_the_data_and_match_the_bf16_form(scale, monkeypatch):
-    """The run-time-shaped convs take their contraction as a two-term fp16 split by default (conv_generic_x3_kernel<.., H2>: a strip is
-    staged as fp32, its own max|x| fixes a power-of-two scale, then it is split in place), as the three-term bf16 split behind
-    CS_NO_FP16X2=1.  Every layer of both against the fp64 oracle at the unchanged tolerance, for crops in [0, 1], raw 8-bit values and
-    values of 1e-3 (fp16's range is 2^-24 .. 65,504: an unscaled split would overflow or vanish); half the matrix instructions; and a
-    cell's result does not depend on what it is screened with."""
+def test_generic_fp16_split_convs_scale_with_the_data(scale):
+    """precision="split16": the run-time-shaped convs take their contraction as a two-term fp16 split (conv_generic_x3_kernel<.., H2>: a
+    strip is staged as fp32, its own max|x| fixes a power-of-two scale, then it is split in place).  Every layer against the fp64 oracle
+    at the unchanged tolerance, for crops in [0, 1], raw 8-bit values and values of 1e-3 (fp16's range is 2^-24 .. 65,504: an unscaled
+    split would overflow or vanish); three 16-bit matrix instructions per (16 px, 16 filters, 32 channels); and a cell's result does
+    not depend on what it is screened with."""
     hw = (64, 128)
     w = synth.random_cae(seed=13, hw=hw, channels=(32, 64, 128, 128, 64, 32, 1), n_enc=3)
     x = (np.concatenate([synth.synth_crops(5, 0, 3, hw=hw), synth.blob_crops(6, 3, hw=hw)]) * np.float32(scale)).astype(np.float32)
     ref = oracle.cae_forward(w, x, acc64=True, layers=True)["layers"]
     names = ["conv1_relu_bn_pool", "conv2_relu_bn_pool", "conv3_relu_bn_pool", "conv4_relu_bn", "conv5_up_relu_bn", "conv6_up_relu_bn"]
-
-    def run():
-        e = Engine.from_weights(w)
-        prof = e.profile()
-        got = [e.layer_output(x, l) for l in range(6)]
-        alone = e.layer_output(x[2:3], 5)
-        e.close()
-        return got, {n: prof[n]["bf16_mfma_per_cell"] for n in names}, alone
-
-    got_h, n_h, alone = run()
-    monkeypatch.setenv("CS_NO_FP16X2", "1")
-    got_b, n_b, _ = run()
+    e = Engine.from_weights(w)
+    prof = e.profile()
+    got = [e.layer_output(x, l) for l in range(6)]
+    alone = e.layer_output(x[2:3], 5)
+    e.close()
+    rows = spec.layer_table(hw, (32, 64, 128, 128, 64, 32, 1), 3)
     for l in range(1, 6):
-        assert n_h[names[l]] * 2 == n_b[names[l]] > 0, (l, n_h, n_b)
+        gh, gw = rows[l]["conv_hw"]
+        taps = 4.0 if l > 3 else 9.0                       # folded upsample: 16 (phase, tap) pairs over a quarter of the grid
+        assert prof[names[l]]["bf16_mfma_per_cell"] == gh * gw / 16 * (rows[l]["cout"] // 16) * taps * (rows[l]["cin"] / 32) * 3, l
+        assert prof[names[l]]["mfma_per_cell"] == 0
     for l in range(6):
-        want = ref[l].reshape(got_h[l].shape)
-        H.assert_close_scaled(got_h[l], want, H.TOL_FEATURES, f"layer {l}, fp16 split, input scale {scale:g}")
-        H.assert_close_scaled(got_b[l], want, H.TOL_FEATURES, f"layer {l}, bf16 split, input scale {scale:g}")
-    assert not np.array_equal(got_h[5], got_b[5])          # the two forms really are different kernels
-    assert np.array_equal(alone[0], got_h[5][2])
+        H.assert_close_scaled(got[l], ref[l].reshape(got[l].shape), H.TOL_FEATURES, f"layer {l}, fp16 split, input scale {scale:g}")
+    assert np.array_equal(alone[0], got[5][2])
 
 
 @pytest.mark.parametrize("channels,expect", [((32, 64, 128, 128, 64, 32, 1), {1, 2, 3, 4, 5}), ((32, 40, 32, 32, 40, 32, 1), {1, 4})])
-def test_split_bf16_convs_against_the_fp32_kernels_and_the_oracle(channels, expect, monkeypatch):
-    """csrc/conv_generic_x3.hip: the MFMA convs of a non-reference architecture take the fp32 contraction on the bf16 matrix
-    pipe where the layer's shape has a plan (cin 32 / 64 / 128; plain and folded-upsample forms; a filter count that is
-    not a multiple of 16).  Every layer against the fp64 oracle at the unchanged tolerance, and against the fp32-MFMA
-    kernels (CS_NO_BF16X3=1): different bits where the split-bf16 kernel ran, the same error class."""
+def test_split16_convs_against_the_fp32_exact_kernels_and_the_oracle(channels, expect):
+    """csrc/conv_generic_x3.hip: with precision="split16" the MFMA convs of a non-reference architecture take the fp32 contraction on
+    the 16-bit matrix pipe where the layer's shape has a plan (cin 32 / 64 / 128; plain and folded-upsample forms; a filter count
+    that is not a multiple of 16).  Every layer against the fp64 oracle at the unchanged tolerance, and against
+    precision="fp32_exact" (the fp32-MFMA kernels): different bits where a split kernel ran, the same error class."""
     hw = (64, 128)
     w = synth.random_cae(seed=13, hw=hw, channels=channels, n_enc=3)
     x = np.concatenate([synth.synth_crops(5, 0, 3, hw=hw), synth.blob_crops(6, 3, hw=hw)])
@@ -147,21 +141,20 @@ def test_split_bf16_convs_against_the_fp32_kernels_and_the_oracle(channels, expe
     assert all(prof[names[l]]["mfma_per_cell"] == 0 for l in on) and all(prof[names[l]]["mfma_per_cell"] > 0 for l in set(range(6)) - on)
     got = [e.layer_output(x, l) for l in range(7)]
     e.close()
-    monkeypatch.setenv("CS_NO_BF16X3", "1")
-    e = Engine.from_weights(w)
-    assert all(v["bf16_mfma_per_cell"] == 0 for v in e.profile().values())
+    e = Engine.from_weights(w, precision="fp32_exact")
+    assert e.precision == "fp32_exact" and all(v["bf16_mfma_per_cell"] == 0 for v in e.profile().values())
     base = [e.layer_output(x, l) for l in range(7)]
     e.close()
     errs = {}
     for l in range(7):
         want = ref[l].reshape(got[l].shape)
-        ea = H.assert_close_scaled(got[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, split-bf16 path")
-        eb = H.assert_close_scaled(base[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, fp32 path")
+        ea = H.assert_close_scaled(got[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, split16")
+        eb = H.assert_close_scaled(base[l], want, H.TOL_FEATURES if l < 6 else H.TOL_RECON, f"layer {l}, fp32_exact")
         errs[l] = (float(f"{ea:.2e}"), float(f"{eb:.2e}"))
         if l in on:
             assert not np.array_equal(got[l], base[l]), l
     assert np.array_equal(got[0], base[0])              # conv1 (cin = 1) is the same kernel either way
-    print("layer: (split-bf16, fp32) max err / max|ref| vs the fp64 oracle:", errs, "split-bf16 layers:", sorted(on))
+    print("layer: (split16, fp32_exact) max err / max|ref| vs the fp64 oracle:", errs, "split16 layers:", sorted(on))
 
 
 def test_separate_encoder_on_the_generic_path(large, crops):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+from cellscreen import _lib as L
 from cellscreen import model_io, spec, synth
 from cellscreen.engine import Engine
 from oracle import oracle
@@ -25,9 +26,15 @@ def det(golden_det):
     return H.det_from_golden(golden_det)
 
 
-@pytest.fixture(scope="module")
-def engine(weights, det):
-    e = Engine.from_weights(weights, None, det)
+PRECISIONS = ["split16", "fp32_exact"]
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def engine(request, weights, det):
+    """Every test that takes `engine` runs in BOTH precisions of cs_model_options at the SAME tolerances: "split16" (the default:
+    two-term fp16 splits on the 16-bit matrix instructions) and "fp32_exact" (every contraction on v_mfma_f32_16x16x4_f32)."""
+    e = Engine.from_weights(weights, None, det, precision=request.param)
+    assert e.precision == request.param
     yield e
     e.close()
 
@@ -63,33 +70,30 @@ def test_each_layer_against_oracle(engine, weights, crops, layer):
         H.assert_close_scaled(got, ref, 1e-5, f"layer {layer}")
 
 
-def test_conv4_split_contractions_are_in_the_fp32_error_class(weights, crops, monkeypatch):
-    """conv4 takes its fp32 contraction on the 16-bit matrix pipe: by default as a two-term fp16 split (three products, exact
-    power-of-two operand scales: conv4_h2_kernel), behind CS_NO_FP16X2 as the three-term bf16 split (six products:
-    conv4_bf16x3_kernel), behind CS_NO_BF16X3 on the fp32 matrix instructions.  Each is compared with a float64 conv of the p3 the
-    SAME engine produced, so only conv4's arithmetic is in the error: all must sit at fp32 rounding level, far inside the 1e-5
-    layer tolerance."""
+def test_conv4_split_contraction_is_in_the_fp32_error_class(weights, crops):
+    """conv4 takes its fp32 contraction on the 16-bit matrix pipe as a two-term fp16 split (three products, exact power-of-two
+    operand scales: conv4_h2_kernel) with precision="split16", on the fp32 matrix instructions with "fp32_exact".  Each is compared
+    with a float64 conv of the p3 the SAME engine produced, so only conv4's arithmetic is in the error: both must sit at fp32
+    rounding level, far inside the 1e-5 layer tolerance."""
     k = weights.kernels[3].astype(np.float64)
     s = weights.bn_gamma[3].astype(np.float64) / np.sqrt(weights.bn_var[3].astype(np.float64) + weights.bn_eps)
 
-    def conv4_error(what):
-        e = Engine.from_weights(weights)
+    def conv4_error(precision):
+        e = Engine.from_weights(weights, precision=precision)
         p3, a4 = e.layer_output(crops, 2), e.layer_output(crops, 3)
-        bf16 = e.profile()["conv4_relu_bn"]["bf16_mfma_per_cell"]
+        prof = e.profile()["conv4_relu_bn"]
         e.close()
         xp = np.pad(p3.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
         z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 8, dx:dx + 8, :], k[dy, dx]) for dy in range(3) for dx in range(3))
         ref = np.maximum(z + weights.biases[3], 0.0) * s + (weights.bn_beta[3] - weights.bn_mean[3] * s)
-        return H.assert_close_scaled(a4, ref, 2e-6, what), bf16, a4
+        return H.assert_close_scaled(a4, ref, 2e-6, "conv4, " + precision), prof, a4
 
-    eh, bfh, h4 = conv4_error("conv4, two-term fp16 split")
-    monkeypatch.setenv("CS_NO_FP16X2", "1")
-    ea, bfa, a4 = conv4_error("conv4, split-bf16 contraction")
-    monkeypatch.setenv("CS_NO_BF16X3", "1")
-    eb, bfb, b4 = conv4_error("conv4, fp32 matrix instructions")
-    assert bfh == 216 and bfa == 432 and bfb == 0                          # the knobs really switch kernels
-    assert not np.array_equal(a4, b4) and not np.array_equal(h4, a4)
-    print(f"conv4 max err / max|ref|: fp16 x2 {eh:.3e}, split-bf16 {ea:.3e}, fp32 MFMA {eb:.3e}")
+    eh, ph, h4 = conv4_error("split16")
+    eb, pb, b4 = conv4_error("fp32_exact")
+    assert ph["bf16_mfma_per_cell"] == 216 and ph["mfma_per_cell"] == 0          # the option really switches kernels
+    assert pb["bf16_mfma_per_cell"] == 0 and pb["mfma_per_cell"] == 576
+    assert not np.array_equal(h4, b4)
+    print(f"conv4 max err / max|ref|: split16 {eh:.3e}, fp32 MFMA {eb:.3e}")
 
 
 @pytest.mark.parametrize("scale", [1.0, 255.0, 3.0e-4, 1.0e6])
@@ -149,18 +153,18 @@ def test_fp16_split_results_do_not_depend_on_the_batch(weights, det):
 
 
 @pytest.mark.parametrize("scale", [1.0, 255.0])
-def test_fused_conv4_conv5_equals_the_two_kernels(weights, scale, monkeypatch):
+def test_fused_conv4_conv5_equals_the_two_kernels(weights, scale):
     """conv4 + conv5 run as one kernel whenever a4 itself is not asked for (conv45_h2_kernel: a4 goes through the same per-cell
     maximum -> power-of-two scale -> [hi | lo] planes inside LDS that conv5_h2_kernel builds from HBM): the same arithmetic in the
-    same order, so a5 and everything downstream are bit-identical to the two-kernel path behind CS_NO_FUSE45=1."""
+    same order, so a5 and everything downstream are bit-identical to the two-kernel path behind CS_DEBUG_NO_FUSE45."""
     x = (oracle.synth_crops(31, 0, 70) * np.float32(scale)).astype(np.float32)
     e = Engine.from_weights(weights)
     a5 = e.layer_output(x, 4)
     a4 = e.layer_output(x, 3)                 # last = 3: the stand-alone conv4
     rec = e.reconstruct(x)
     e.close()
-    monkeypatch.setenv("CS_NO_FUSE45", "1")
-    e2 = Engine.from_weights(weights)
+    e2 = Engine.from_weights(weights, debug_flags=L.DEBUG_NO_FUSE45)
+    assert e2.info.debug_flags == L.DEBUG_NO_FUSE45
     try:
         assert np.array_equal(e2.layer_output(x, 3), a4)
         assert np.array_equal(e2.layer_output(x, 4), a5)
@@ -171,11 +175,11 @@ def test_fused_conv4_conv5_equals_the_two_kernels(weights, scale, monkeypatch):
         e2.close()
 
 
-def test_small_calls_run_the_detector_tail_split_with_identical_results(weights, det, monkeypatch):
+def test_small_calls_run_the_detector_tail_split_with_identical_results(weights, det):
     """A call of at most 16,384 cells runs the PCA GEMM's feature ranges and the SVMs' support-vector ranges side by side in separate
     workgroups (a 128-cell call is otherwise two workgroups / one workgroup walking everything in sequence) and adds the range sums in
     the order the one-workgroup kernels add them: every output is bit-identical to the same cells screened inside a large call, and to
-    the one-workgroup form forced by CS_NO_SMALL_SPLIT=1."""
+    the one-workgroup form forced by CS_DEBUG_NO_SMALL_SPLIT."""
     n_big = 16384 + 700
     x = oracle.synth_crops(23, 0, n_big)
     e = Engine.from_weights(weights, None, det)
@@ -191,9 +195,7 @@ def test_small_calls_run_the_detector_tail_split_with_identical_results(weights,
                 assert np.array_equal(part[k], whole[k][idx]), (k, idx)
     finally:
         e.close()
-    monkeypatch.setenv("CS_NO_SMALL_SPLIT", "1")
-    e1 = Engine.from_weights(weights, None, det)
-    monkeypatch.delenv("CS_NO_SMALL_SPLIT")
+    e1 = Engine.from_weights(weights, None, det, debug_flags=L.DEBUG_NO_SMALL_SPLIT)
     try:
         one = e1.screen(x[:300])
         for k in whole:
@@ -202,36 +204,34 @@ def test_small_calls_run_the_detector_tail_split_with_identical_results(weights,
         e1.close()
 
 
-def test_conv3_winograd_on_the_16_bit_pipe_is_in_the_fp32_error_class(weights, crops, monkeypatch):
-    """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs as a two-term fp16 split by default
-    (conv3_wino_h2_kernel, 768 MFMAs per cell), as the three-term bf16 split behind CS_NO_FP16X2 (conv3_wino_x3_kernel, 1,536) and on
-    fp32 MFMAs behind CS_NO_BF16X3_CONV3=1: each against a float64 conv + ReLU + BN + max-pool of the p2 the SAME engine made."""
+def test_conv3_winograd_on_the_16_bit_pipe_is_in_the_fp32_error_class(weights, crops):
+    """conv3 = the feature vector.  Its Winograd F(2x2,3x3) contraction runs as a two-term fp16 split with precision="split16"
+    (conv3_wino_h2_kernel, 768 MFMAs per cell) and on fp32 MFMAs with "fp32_exact" (2,048): each against a float64 conv + ReLU + BN +
+    max-pool of the p2 the SAME engine made."""
     k = weights.kernels[2].astype(np.float64)
     s = weights.bn_gamma[2].astype(np.float64) / np.sqrt(weights.bn_var[2].astype(np.float64) + weights.bn_eps)
 
-    def conv3_error(what):
-        e = Engine.from_weights(weights)
+    def conv3_error(precision):
+        e = Engine.from_weights(weights, precision=precision)
         p2, p3 = e.layer_output(crops, 1), e.layer_output(crops, 2)
-        bf16 = e.profile()["conv3_relu_bn_pool"]["bf16_mfma_per_cell"]
+        prof = e.profile()["conv3_relu_bn_pool"]
         e.close()
         xp = np.pad(p2.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
         z = sum(np.einsum("nyxc,co->nyxo", xp[:, dy:dy + 16, dx:dx + 16, :], k[dy, dx]) for dy in range(3) for dx in range(3))
         a = np.maximum(z + weights.biases[2], 0.0) * s + (weights.bn_beta[2] - weights.bn_mean[2] * s)
         ref = a.reshape(len(a), 8, 2, 8, 2, 32).max(axis=(2, 4))
-        return H.assert_close_scaled(p3, ref, 3e-6, what), bf16, p3
+        return H.assert_close_scaled(p3, ref, 3e-6, "conv3, " + precision), prof, p3
 
-    eh, bfh, h3 = conv3_error("conv3, Winograd as a two-term fp16 split")
-    monkeypatch.setenv("CS_NO_FP16X2", "1")
-    ea, bfa, a3 = conv3_error("conv3, Winograd on bf16 MFMAs")
-    monkeypatch.setenv("CS_NO_BF16X3_CONV3", "1")
-    eb, bfb, b3 = conv3_error("conv3, Winograd on fp32 MFMAs")
-    assert bfh == 768 and bfa == 1536 and bfb == 0 and not np.array_equal(a3, b3) and not np.array_equal(h3, a3)
-    print(f"conv3 max err / max|ref|: fp16 x2 {eh:.3e}, bf16 MFMAs {ea:.3e}, fp32 MFMAs {eb:.3e}")
+    eh, ph, h3 = conv3_error("split16")
+    eb, pb, b3 = conv3_error("fp32_exact")
+    assert ph["bf16_mfma_per_cell"] == 768 and ph["mfma_per_cell"] == 0 and pb["bf16_mfma_per_cell"] == 0 and pb["mfma_per_cell"] == 2048
+    assert not np.array_equal(h3, b3)
+    print(f"conv3 max err / max|ref|: split16 {eh:.3e}, fp32 MFMAs {eb:.3e}")
 
 
 @pytest.mark.parametrize("n", [1, 3, 769, 1537])
-def test_bottleneck_split_bf16_kernels_at_odd_cell_counts(weights, n):
-    """conv4 / conv5 (csrc/conv45_bf16x3.hip) are persistent workgroups that prefetch the next cell while one is in the matrix
+def test_bottleneck_split_kernels_at_odd_cell_counts(weights, n):
+    """conv4 / conv5 (csrc/conv45_h2.hip) are persistent workgroups that prefetch the next cell while one is in the matrix
     phase: counts below, at and past their resident grids (2 and 1 workgroups per CU x 256 CUs) against the oracle."""
     x = synth.synth_crops(23, 4242, n)
     ref = oracle.cae_forward(weights, x, acc64=True, layers=True)["layers"]
@@ -243,9 +243,10 @@ def test_bottleneck_split_bf16_kernels_at_odd_cell_counts(weights, n):
         e.close()
 
 
-def test_golden_cae_vectors(golden_cae):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_golden_cae_vectors(golden_cae, precision):
     g = golden_cae
-    e = Engine.from_weights(H.cae_from_golden(g))
+    e = Engine.from_weights(H.cae_from_golden(g), precision=precision)
     feats = e.encode(g["crops"], which=0)
     H.assert_close_scaled(feats, g["features"], H.TOL_FEATURES, "golden features")
     rec, mse, mae = e.reconstruct(g["crops"])
@@ -364,6 +365,45 @@ def test_extreme_inputs(engine, weights):
     assert np.abs(rec.astype(np.float64) - ref["recon"]).max() <= H.TOL_RECON
     H.assert_rel(mse, ref["mse"], H.TOL_ERR_REL, "mse")
     H.assert_close_scaled(engine.encode(x, which=0), ref["features"], H.TOL_FEATURES, "features")
+
+
+def test_non_finite_and_negative_crops_inside_a_batch(engine, weights, det):
+    """A NaN crop, a crop with one +Inf pixel and a negative crop inside a batch of 40 (both precisions).  The reference would raise
+    for the whole call (pca.transform: "Input X contains NaN", improved_detection.py:135); here the non-finite cell alone is marked --
+    mse / mae NaN or Inf (NumPy's mean over a non-finite difference, :126-127), both scores NaN, both flags -1 -- and EVERY other
+    cell is bit-identical to the batch without it (the persistent workgroups carry LDS images from cell to cell: the pixel is
+    taken as 0 when a crop is staged).  A negative crop is an ordinary input: oracle parity at the usual bars."""
+    x = oracle.synth_crops(19, 0, 40)
+    x[7] = -x[7]                                            # a negative crop
+    clean = engine.screen(x)
+    ref = oracle.screen(weights, None, det, x[7:8], acc64=True)
+    H.assert_rel(clean["mse"][7:8], ref["mse"], H.TOL_ERR_REL, "mse of the negative crop")
+    assert abs(clean["cons_score"][7] - ref["cons_score"][0]) <= H.TOL_DEC_E2E * np.abs(det.conservative.dual_coef).sum()
+    for poison in ("nan_crop", "inf_pixel", "nan_pixel_first_cell", "nan_pixel_last_cell"):
+        y = x.copy()
+        if poison == "nan_crop":
+            bad = 13; y[bad] = np.nan
+        elif poison == "inf_pixel":
+            bad = 22; y[bad, 31, 5] = np.inf
+        elif poison == "nan_pixel_first_cell":
+            bad = 0; y[bad, 0, 0] = np.nan
+        else:
+            bad = 39; y[bad, 63, 63] = -np.inf
+        for inp in (y, np.concatenate([y] * 20)):           # 40 cells: one per workgroup; 800: cells follow each other in a workgroup
+            r = engine.screen(inp)
+            for rep in range(len(inp) // 40):
+                sl = slice(40 * rep, 40 * rep + 40)
+                assert not np.isfinite(r["mse"][sl][bad]) and not np.isfinite(r["mae"][sl][bad]), poison
+                assert np.isnan(r["cons_score"][sl][bad]) and np.isnan(r["mod_score"][sl][bad]), poison
+                assert r["cons_pred"][sl][bad] == -1 and r["mod_pred"][sl][bad] == -1
+                keep = np.arange(40) != bad
+                for k in clean:
+                    assert np.array_equal(r[k][sl][keep], clean[k][keep]), (poison, k, rep)
+        # the other entry points: features / reconstruction errors of the other cells are untouched too
+        f = engine.encode(y, which=0)
+        assert np.array_equal(f[keep], engine.encode(x, which=0)[keep]) and np.isfinite(f).all()
+        _, mse, _ = engine.reconstruct(y, want_recon=False)
+        assert np.array_equal(mse[keep], clean["mse"][keep]) and not np.isfinite(mse[bad])
 
 
 def test_negative_bn_scale(det):
@@ -537,12 +577,12 @@ def test_automatic_chunk_by_input_kind(weights, det):
 
 def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
     """conv1 + conv2 run as ONE kernel (conv12_fused.hip: conv2 as Winograd F(4x4,3x3), p1 rows produced into an LDS ring and
-    never written to HBM; conv1 inside it on bf16 MFMAs with the input's three bf16 planes packed along K, or on fp32 MFMAs
-    behind CS_NO_BF16X3_CONV1=1) whenever p1 itself is not asked for.  Every element of p2 -- 600 cells = more than two cells per
+    never written to HBM; both contractions as two-term fp16 splits with precision="split16", on fp32 MFMAs with "fp32_exact")
+    whenever p1 itself is not asked for.  Every element of p2 -- 600 cells = more than two cells per
     persistent workgroup (256 CUs x 1), so the ring wrap between cells, the crop prefetch and every workgroup are
-    covered -- against the fp64-evaluated oracle at the layer bar, and against the two-kernel path (CS_NO_FUSE12=1:
-    conv1 kernel -> p1 in HBM -> F(2x2,3x3) conv2).  p1 of the stand-alone conv1 kernel (what layer_output(0) and
-    training use) gets the same full-coverage compare: 600 cells = 2,400 strips > 2 x its 1,024 resident workgroups."""
+    covered -- against the fp64-evaluated oracle at the layer bar, in both precisions, and against the two-kernel path
+    (CS_DEBUG_NO_FUSE12: conv1 kernel -> p1 in HBM -> F(2x2,3x3) conv2).  p1 of the stand-alone conv1 kernel (what layer_output(0)
+    and training use) gets the same full-coverage compare: 600 cells = 2,400 strips > 2 x its 1,024 resident workgroups."""
     n = 600
     x = synth.synth_crops(11, 7000, n)
     x[0] = 0.0
@@ -552,23 +592,15 @@ def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
     x[4:40] = synth.blob_crops(5, 36)
     ref = oracle.cae_forward(weights, x, acc64=True, want=("features",), layers=True)["layers"]
     e = Engine.from_weights(weights)
-    os.environ["CS_NO_FUSE12"] = "1"
-    try:
-        e2 = Engine.from_weights(weights)
-    finally:
-        del os.environ["CS_NO_FUSE12"]
-    os.environ["CS_NO_BF16X3_CONV1"] = "1"                 # the fused kernel with conv1 on the fp32 matrix instructions
-    try:
-        e3 = Engine.from_weights(weights)
-    finally:
-        del os.environ["CS_NO_BF16X3_CONV1"]
+    e2 = Engine.from_weights(weights, debug_flags=L.DEBUG_NO_FUSE12)
+    e3 = Engine.from_weights(weights, precision="fp32_exact")        # the fused kernel on the fp32 matrix instructions
     try:
         p1 = e.layer_output(x, 0)
         p2 = e.layer_output(x, 1)
         p2_two = e2.layer_output(x, 1)
         p2_c1f32 = e3.layer_output(x, 1)
-        # conv1 as a two-term fp16 split: 66 conv rows x 8 (x-tile, slice) x 2 MFMAs = 1,056 16-bit MFMAs per cell (1,584 as three bf16
-        # ones); conv2 likewise: 36 points x 4 tile groups x 4 slices x 3 products = 1,728 more
+        # conv1 as a two-term fp16 split: 66 conv rows x 8 (x-tile, slice) x 2 MFMAs = 1,056 16-bit MFMAs per cell;
+        # conv2 likewise: 36 points x 4 tile groups x 4 slices x 3 products = 1,728 more
         assert e.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 1056 + 1728 and e.profile()["conv1_conv2_fused"]["mfma_per_cell"] == 0
         assert e3.profile()["conv1_conv2_fused"]["bf16_mfma_per_cell"] == 0 and e3.profile()["conv1_conv2_fused"]["mfma_per_cell"] > 4608
     finally:
@@ -578,10 +610,10 @@ def test_fused_conv1_conv2_every_output_of_more_than_two_residencies(weights):
     ef = np.abs(p2.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
     et = np.abs(p2_two.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
     e3f = np.abs(p2_c1f32.astype(np.float64) - ref[1]).max(axis=(1, 2, 3)) / s2
-    print("p1 max err / range %.2e; p2 fused %.2e (worst cell %d), fused with conv1 on fp32 MFMAs %.2e, two-kernel %.2e"
+    print("p1 max err / range %.2e; p2 fused %.2e (worst cell %d), fused on fp32 MFMAs %.2e, two-kernel %.2e"
           % (e1.max(), ef.max(), int(ef.argmax()), e3f.max(), et.max()))
     assert e3f.max() <= 1e-5 and not np.array_equal(p2, p2_c1f32)
     assert e1.max() <= 1e-5, f"conv1: cell {int(e1.argmax())}"
     assert et.max() <= 1e-5
     assert ef.max() <= 1e-5, f"fused conv1+conv2: cell {int(ef.argmax())} off by {ef.max():.3e} of the range"
-    assert not np.array_equal(p2, p2_two), "the knob did not select a different kernel"
+    assert not np.array_equal(p2, p2_two), "the debug flag did not select a different kernel"

@@ -303,6 +303,52 @@ def test_trainer_refuses_shapes_its_kernels_would_get_wrong():
     Trainer(synth.random_cae(seed=1, hw=(64, 128), channels=(8, 16, 32, 32, 16, 8, 1), trivial_bn=True)).close()
 
 
+def test_batch_statistics_of_a_nearly_constant_channel():
+    """the forward conv's epilogue takes the BatchNormalization batch statistics in one pass.  A channel whose variance
+    is far below mean^2 (here relu(conv) = 50 +- 1e-4: variance ~1e-9 of mean^2) loses its M2 to the rounding of the squares unless
+    the sums run about a shift; the BN output computed from the trainer's own relu tensors in float64 says which."""
+    w = synth.random_cae(seed=5)
+    for l, c in ((1, 7), (3, 11), (4, 3)):
+        w.kernels[l][..., c] *= np.float32(2e-5)
+        w.biases[l][c] = np.float32(50.0)
+    x, y = batch(32, seed=4)
+    tr = Trainer(w)
+    tr.forward_backward(x, y)
+    for l in (1, 3, 4):
+        r = tr.tensor(0, l, 32).astype(np.float64)
+        a = tr.tensor(1, l, 32).astype(np.float64)
+        mu, var = r.mean(axis=(0, 1, 2)), r.var(axis=(0, 1, 2))
+        ref = (r - mu) / np.sqrt(var + w.bn_eps) * w.bn_gamma[l].astype(np.float64) + w.bn_beta[l].astype(np.float64)
+        if l < 3:
+            N, Hh, Ww, Cc = ref.shape
+            ref = ref.reshape(N, Hh // 2, 2, Ww // 2, 2, Cc).max(axis=(2, 4))
+        c = {1: 7, 3: 11, 4: 3}[l]
+        assert var[c] < 1e-6 * mu[c] ** 2, (l, var[c], mu[c])
+        err = np.abs(a - ref).max(axis=(0, 1, 2))
+        print("layer", l, "var of the flat channel %.3e" % var[c], "BN output err: flat channel %.2e, others %.2e" % (err[c], np.delete(err, c).max()))
+        assert err.max() <= 2e-4, (l, int(err.argmax()), err.max())
+    tr.close()
+
+
+def test_trainer_refuses_an_oversized_batch():
+    """conv7's loss epilogue leaves 4 bias-gradient partials per cell in a buffer sized once; a batch beyond what it
+    (and the 2^31 indexing of the BatchNormalization kernels) holds is refused at the entry of every step call, before anything
+    is allocated or launched."""
+    from cellscreen._lib import CellScreenError
+    import ctypes as C
+    tr = Trainer(synth.random_cae(seed=3))
+    x = np.zeros((1, 64, 64), np.float32)
+    lo, ma = C.c_float(), C.c_float()
+    for call in (lambda n: tr._lib.cs_train_step(tr._h, x.ctypes.data, x.ctypes.data, n, 0, 1e-3, C.byref(lo), C.byref(ma)),
+                 lambda n: tr._lib.cs_train_step_async(tr._h, x.ctypes.data, x.ctypes.data, n, 0, 1e-3),
+                 lambda n: tr._lib.cs_train_forward_backward(tr._h, x.ctypes.data, x.ctypes.data, n, 0, C.byref(lo), C.byref(ma))):
+        for n in (8193, 20000, 70000):
+            assert call(n) == -6, n        # CS_ERR_UNSUPPORTED, without reading x
+    xb, yb = batch(32)
+    tr.step(xb, yb)                        # and the trainer still works
+    tr.close()
+
+
 def test_create_anomaly_detector_with_the_reference_signature_alone(tmp_path):
     """create_anomaly_detector(encoder, cell_images) (CAE_improved_modeltrain.py:394) on a fresh instance: no training run, no
     autoencoder argument -- the encoder weight set alone is enough to fit and save the detector."""

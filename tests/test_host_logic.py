@@ -27,10 +27,42 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), f"libcellscreen.so does not export {n}"
     assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES out of sync with include/cellscreen.h"
-    assert lib.cs_abi_version() == 1
+    assert lib.cs_abi_version() == 2
     assert lib.cs_profile_kernel_count() == 13 and lib.cs_profile_kernel_name(12) == b"conv1_conv2_fused"
     assert lib.cs_profile_kernel_name(1) == b"conv2_relu_bn_pool"
     assert lib.cs_status_string(-4) == b"no usable gfx950 device"
+
+
+def test_model_options_are_validated_before_any_device_work():
+    """cs_model_options (ABI version 2): precision is an argument of the handle, not an environment variable.  Bad options are
+    CS_ERR_INVALID before the device is looked at; the struct mirrors include/cellscreen.h."""
+    import ctypes as C
+    from cellscreen.engine import _fill_cae
+    lib = L.load_library()
+    assert C.sizeof(L.CSModelOptions) == 32 and L.PRECISION_SPLIT16 == 0 and L.PRECISION_FP32_EXACT == 1
+    keep, h = [], C.c_void_p()
+    w = _fill_cae(synth.random_cae(), keep)
+    for bad in (dict(precision=2), dict(precision=-1), dict(debug_flags=0x10), dict(struct_size=4), dict(reserved0=1)):
+        o = L.model_options()
+        for k, v in bad.items():
+            if k == "reserved0":
+                o.reserved[0] = v
+            else:
+                setattr(o, k, v)
+        assert lib.cs_model_from_arrays(C.byref(w), None, None, 0, C.byref(o), C.byref(h)) == -1, bad
+        assert b"cs_model_options" in lib.cs_last_error()
+    with pytest.raises(ValueError):
+        L.model_options("bf16")
+    for name, val in (("split16", 0), ("fp32_exact", 1), ("exact", 1)):
+        assert L.model_options(name).precision == val
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cellscreen.h")).read()
+    assert "CS_PRECISION_SPLIT16 = 0" in hdr and "CS_PRECISION_FP32_EXACT = 1" in hdr
+    # nothing but the two debug overrides reads the environment to choose arithmetic
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cell-image-analysis_amd", "csrc")
+    envs = set()
+    for f in os.listdir(csrc):
+        envs |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    assert envs <= {"CS_DEBUG_PRECISION", "CS_DEBUG_FLAGS", "CS_C12_DIAG", "CS_WINO_DIAG"}, envs
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -58,24 +90,24 @@ def test_product_package_never_touches_the_oracle():
 def test_bad_arguments_are_rejected_before_any_device_work():
     lib = L.load_library()
     h = C.c_void_p()
-    assert lib.cs_model_load(b"/nonexistent/dir", 0, C.byref(h)) == -2          # CS_ERR_IO
+    assert lib.cs_model_load(b"/nonexistent/dir", 0, None, C.byref(h)) == -2          # CS_ERR_IO
     assert b"cannot open" in lib.cs_last_error()
     w = synth.random_cae()
     w.kernels[1] = np.zeros((3, 3, 32, 48), np.float32)                          # not the reference graph
     from cellscreen.engine import _fill_cae
     keep = []
     s = _fill_cae(w, keep)
-    assert lib.cs_model_from_arrays(C.byref(s), None, None, 0, C.byref(h)) == -6  # CS_ERR_UNSUPPORTED
-    assert lib.cs_model_from_arrays(None, None, None, 0, C.byref(h)) == -1       # CS_ERR_INVALID
+    assert lib.cs_model_from_arrays(C.byref(s), None, None, 0, None, C.byref(h)) == -6  # CS_ERR_UNSUPPORTED
+    assert lib.cs_model_from_arrays(None, None, None, 0, None, C.byref(h)) == -1       # CS_ERR_INVALID
     # the architecture is judged before the device is touched: a non-reference instance of the layer grammar
     # that the generic kernels cover gets as far as "no device" here; one outside the grammar is refused
     big = synth.random_cae(seed=5, hw=(128, 128), channels=(32, 64, 128, 128, 64, 32, 1), n_enc=3)
-    rc = lib.cs_model_from_arrays(C.byref(_fill_cae(big, keep)), None, None, 0, C.byref(h))
+    rc = lib.cs_model_from_arrays(C.byref(_fill_cae(big, keep)), None, None, 0, None, C.byref(h))
     assert rc == (-4 if lib.cs_device_count() <= 0 else 0)
     if rc == 0:
         lib.cs_model_free(h)
     odd = synth.random_cae(seed=5, hw=(64, 64), channels=(32, 64, 32, 32, 1), n_enc=3)           # n_conv != 2 n_enc + 1
-    assert lib.cs_model_from_arrays(C.byref(_fill_cae(odd, keep)), None, None, 0, C.byref(h)) == -6
+    assert lib.cs_model_from_arrays(C.byref(_fill_cae(odd, keep)), None, None, 0, None, C.byref(h)) == -6
     assert b"grammar" in lib.cs_last_error()
 
 
@@ -97,7 +129,7 @@ def test_model_dir_round_trip(tmp_path, golden_det):
     with open(os.path.join(d, "cae.bin"), "r+b") as f:
         f.seek(0); f.write(b"XXXX")
     h = C.c_void_p()
-    assert L.load_library().cs_model_load(d.encode(), 0, C.byref(h)) == -3       # CS_ERR_FORMAT
+    assert L.load_library().cs_model_load(d.encode(), 0, None, C.byref(h)) == -3       # CS_ERR_FORMAT
 
 
 def test_reference_pickles_convert(tmp_path, golden_det):
