@@ -29,10 +29,15 @@ Rank 0 prints ONE JSON line; besides the contract keys it carries
                 Keras/TF if importable, else its counterpart -- the same graph in torch-CPU at Keras's
                 predict batch of 32, autoencoder pass + separate encoder pass, NumPy MSE/MAE, the real
                 scikit-learn transform / predict / decision_function calls (4 SVM passes) -- on
-                configs[0]'s 128 crops and on 4,096; plus the OpenMP oracle port (rank 0, N = 1 only)
-  exact_fp32    the same step with every contraction on the fp32 matrix instructions (a second engine under CS_NO_BF16X3=1):
-                the headline runs the fp32 contractions as split 16-bit products (dtype says so), this is the bit-for-bit
-                fp32-MFMA form next to it
+                configs[0]'s 128 crops and on 4,096, each at the best of a sweep over the host's thread counts (the sweep is in
+                the line); plus the OpenMP oracle port (rank 0, N = 1 only)
+  exact_fp32    the same step -- same --steps / --warmup, the same 18 B/cell copy to the host and synchronisation -- on a second engine
+                created with precision="fp32_exact" (cs_model_options: every contraction on the fp32 matrix instructions), with its
+                own parity_on_cpu_sample: the headline runs the fp32 contractions as split 16-bit products (dtype says so), this is
+                the reference's fp32 arithmetic next to it
+  large_variant BASELINE.json configs[4]'s single-GPU half: 8,192 crops 128x128 through the 32-64-128 | 128-64-32-1 instance of the
+                layer grammar (forward + MSE/MAE: cells/s, per-kernel fractions of the 16-bit matrix peak) and 200 batch-32 training
+                steps of the run-time-shaped trainer (ms/step, algorithmic TFLOP/s)
   e2e_raw       the production path end to end: 1 M RAW uint16 bounding-box crops (sides U[32,100]) in pinned host memory ->
                 H2D -> cs_preprocess (CLAHE + anti-aliased resize, improved_detection.py:98-99) -> cs_screen -> 18 B/cell on the
                 host, the copy of chunk i + 1 under the kernels of chunk i
@@ -88,7 +93,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="cells for the CPU port baseline (0 = auto, ~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic with rocprofv3 child passes")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the training leg and the small-N latency leg")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the exact-fp32, raw-crop, training, 128x128-variant and small-N legs")
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = one configs[1] epoch: 1,250)")
     ap.add_argument("--raw-crops", type=int, default=1_000_000, help="raw crops of the e2e_raw leg")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -227,10 +232,27 @@ def _keras_models(weights):
     return (lambda X: ae.predict(X, verbose=0)), (lambda X: en.predict(X, verbose=0)), np
 
 
-def cpu_reference_sequence(weights, sk, seed, sizes=(128, 4096)):
+def _host_cpu_budget():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup's CPU quota when there is one (a GPU box gives a
+    1-GPU job a share of a 256-CPU host: 128 torch threads on a 16-CPU quota is oversubscription, not a baseline)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return avail, quota
+
+
+def cpu_reference_sequence(weights, sk, seed, sizes=(128, 4096), threads=(4, 8, 16, 32, 64, 128), sweep_crops=512):
     """improved_detection.py:122-142 literally, on the host: X -> autoencoder.predict -> MSE/MAE -> encoder.predict ->
     flatten -> scaler.transform -> pca.transform -> 2x predict + 2x decision_function.  sk = the fitted scikit-learn
-    objects.  Keras/TF when importable ("reference"), else torch-CPU for the two predict calls ("counterpart")."""
+    objects.  Keras/TF when importable ("reference"), else torch-CPU for the two predict calls ("counterpart").
+    The intra-op thread count is SWEPT (a 512-crop run per candidate, seconds each), each size is then timed at the best
+    count, and the sweep is reported beside the value: at Keras's predict batch of 32 more threads than the host gives this job
+    only adds contention."""
     import numpy as np
     import torch
     from cellscreen import synth
@@ -245,38 +267,63 @@ def cpu_reference_sequence(weights, sk, seed, sizes=(128, 4096)):
         en_predict = lambda X: predict(en, X).transpose(0, 2, 3, 1)                      # noqa: E731
         to_in = lambda X: torch.from_numpy(np.ascontiguousarray(X.transpose(0, 3, 1, 2)))  # noqa: E731
     scaler, pca, dets = sk["scaler"], sk["pca"], sk["detectors"]
+
+    def run(cells):
+        t0 = time.perf_counter()
+        X = np.expand_dims(np.array(cells), axis=-1).astype("float32")                  # :122
+        Xin = to_in(X)
+        rec = ae_predict(Xin)                                                          # :125
+        mse = np.mean(np.square(X - rec), axis=(1, 2, 3))                               # :126
+        mae = np.mean(np.abs(X - rec), axis=(1, 2, 3))                                  # :127
+        t1 = time.perf_counter()
+        enc = en_predict(Xin)                                                          # :130
+        flat = np.ascontiguousarray(enc).reshape(len(enc), -1)                          # :131
+        t2 = time.perf_counter()
+        red = pca.transform(scaler.transform(flat))                                     # :134-135
+        t3 = time.perf_counter()
+        cp = dets["Conservative"].predict(red); mp = dets["Moderate"].predict(red)      # :138-139
+        cs = dets["Conservative"].decision_function(red); ms = dets["Moderate"].decision_function(red)   # :141-142
+        t4 = time.perf_counter()
+        n = len(cells)
+        rec_ = dict(cells_per_s=round(n / (t4 - t0), 1), wall_ms=round((t4 - t0) * 1e3, 2),
+                    split_ms=dict(autoencoder_predict_and_errors=round((t1 - t0) * 1e3, 2), encoder_predict=round((t2 - t1) * 1e3, 2),
+                                  scaler_pca=round((t3 - t2) * 1e3, 2), svm_4_calls=round((t4 - t3) * 1e3, 2)))
+        return rec_, dict(mse=mse, mae=mae, cons_score=-cs, mod_score=-ms, cons_pred=cp, mod_pred=mp)
+
+    avail, quota = _host_cpu_budget()
+    default_threads = torch.get_num_threads()
+    cand = sorted({t for t in threads if t <= avail} | {min(avail, default_threads)})
+    sweep = {}
     out = {}
     last = None
-    for n in sizes:
-        cells = list(synth.synth_crops(seed, 0, n))
-        best = None
-        for rep in range(2 if n <= 512 else 1):                   # the small case twice: the first call pays one-time set-up
-            t0 = time.perf_counter()
-            X = np.expand_dims(np.array(cells), axis=-1).astype("float32")                  # :122
-            Xin = to_in(X)
-            rec = ae_predict(Xin)                                                          # :125
-            mse = np.mean(np.square(X - rec), axis=(1, 2, 3))                               # :126
-            mae = np.mean(np.abs(X - rec), axis=(1, 2, 3))                                  # :127
-            t1 = time.perf_counter()
-            enc = en_predict(Xin)                                                          # :130
-            flat = np.ascontiguousarray(enc).reshape(len(enc), -1)                          # :131
-            t2 = time.perf_counter()
-            red = pca.transform(scaler.transform(flat))                                     # :134-135
-            t3 = time.perf_counter()
-            cp = dets["Conservative"].predict(red); mp = dets["Moderate"].predict(red)      # :138-139
-            cs = dets["Conservative"].decision_function(red); ms = dets["Moderate"].decision_function(red)   # :141-142
-            t4 = time.perf_counter()
-            rec_ = dict(cells_per_s=round(n / (t4 - t0), 1), wall_ms=round((t4 - t0) * 1e3, 2),
-                        split_ms=dict(autoencoder_predict_and_errors=round((t1 - t0) * 1e3, 2), encoder_predict=round((t2 - t1) * 1e3, 2),
-                                      scaler_pca=round((t3 - t2) * 1e3, 2), svm_4_calls=round((t4 - t3) * 1e3, 2)))
-            if best is None or rec_["wall_ms"] < best["wall_ms"]:
-                best = rec_
-            last = dict(mse=mse, mae=mae, cons_score=-cs, mod_score=-ms, cons_pred=cp, mod_pred=mp)
-        out[str(n)] = best
+    try:
+        for n in sizes:
+            cells_sw = list(synth.synth_crops(seed, 0, min(n, sweep_crops)))
+            sw = {}
+            for t in cand:
+                torch.set_num_threads(t)
+                run(cells_sw[:64])                                     # thread pool of this size up, pages in
+                sw[str(t)] = run(cells_sw)[0]["cells_per_s"]
+            best_t = int(max(sw, key=lambda k: sw[k]))
+            sweep[str(n)] = dict(crops=len(cells_sw), cells_per_s_by_threads=sw, best_threads=best_t)
+            torch.set_num_threads(best_t)
+            cells = list(synth.synth_crops(seed, 0, n))
+            best = None
+            for rep in range(2 if n <= 512 else 1):                   # the small case twice: the first call pays one-time set-up
+                rec_, res = run(cells)
+                if best is None or rec_["wall_ms"] < best["wall_ms"]:
+                    best = rec_
+                last = res
+            best["torch_threads"] = best_t
+            out[str(n)] = best
+    finally:
+        torch.set_num_threads(default_threads)
     big = out[str(sizes[-1])]
-    return dict(value=big["cells_per_s"], unit="cells/s", cores=torch.get_num_threads(), kind=kind, label=label,
-                sample="%d crops (seed %d); also BASELINE.json configs[0]'s 128 crops: %.1f cells/s" % (sizes[-1], seed, out[str(sizes[0])]["cells_per_s"]),
-                sizes=out, host_cpu_count=os.cpu_count(), torch_threads=torch.get_num_threads(),
+    return dict(value=big["cells_per_s"], unit="cells/s", cores=big["torch_threads"], kind=kind, label=label,
+                sample="%d crops (seed %d) at the best intra-op thread count of the sweep; also BASELINE.json configs[0]'s 128 crops: %.1f cells/s at %d threads"
+                       % (sizes[-1], seed, out[str(sizes[0])]["cells_per_s"], out[str(sizes[0])]["torch_threads"]),
+                sizes=out, thread_sweep=sweep, host_cpu_count=os.cpu_count(), host_cpus_in_affinity_mask=avail, cgroup_cpu_quota=quota,
+                torch_threads=big["torch_threads"], torch_threads_default=default_threads,
                 omp_num_threads=os.environ.get("OMP_NUM_THREADS"), cpu_model=_cpu_model()), last
 
 
@@ -346,28 +393,111 @@ def train_leg(steps, local_rank, seed):
                 val_loss=None if val_loss is None else round(val_loss, 6))
 
 
-def exact_fp32_leg(weights, det, x, out, args, local_rank):
-    """The same step on the fp32 matrix instructions throughout (CS_NO_BF16X3=1 selects the fp32-MFMA kernels at model creation)."""
+def exact_fp32_leg(weights, det, x, out, host, args, local_rank):
+    """The headline step on a second engine created with precision="fp32_exact" (cs_model_options: every contraction on
+    v_mfma_f32_16x16x4_f32 -- the reference's float32 arithmetic, improved_detection.py:122,125,130): the same --steps / --warmup,
+    the same 18 B/cell copy into pinned host memory and the same synchronisation as step().  Returns the leg and the results'
+    first 65,536 cells (for its own parity check against the CPU oracle)."""
     import torch
     from cellscreen.engine import Engine
-    os.environ["CS_NO_BF16X3"] = "1"
-    try:
-        e = Engine.from_weights(weights, None, det, device_id=local_rank)
-    finally:
-        del os.environ["CS_NO_BF16X3"]
+    e = Engine.from_weights(weights, None, det, device_id=local_rank, precision="fp32_exact")
+    assert e.precision == "fp32_exact"
+
+    def step():
+        e.screen(x, out=out, out_device=True)
+        for k, v in out.items():
+            host[k].copy_(v, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+
     try:
         e.set_chunk(args.chunk)
-        e.screen(x, out=out, out_device=True)
+        for _ in range(max(1, args.warmup)):
+            step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(3):
-            e.screen(x, out=out, out_device=True)
+        for _ in range(args.steps):
+            step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
+        dt = (time.perf_counter() - t0) / args.steps
+        head = {k: v[:65536].clone().numpy() for k, v in host.items()}
     finally:
         e.close()
-    return dict(value=round(len(x) / dt, 1), unit="cells/s", ms_per_step=round(dt * 1e3, 3), steps=3, dtype="f32 (v_mfma_f32_16x16x4_f32 for every contraction)",
-                note="results stay on the device in this leg (no 18 B/cell copy)")
+    return dict(value=round(len(x) / dt, 1), unit="cells/s", ms_per_step=round(dt * 1e3, 3), steps=args.steps, warmup=max(1, args.warmup),
+                precision="fp32_exact", dtype="f32 (v_mfma_f32_16x16x4_f32 for every contraction; SVM fp64)",
+                note="same step as the headline: results end in pinned host memory, stream synchronised"), head
+
+
+def large_variant_leg(local_rank, seed, n=8192, train_steps=200):
+    """BASELINE.json configs[4], the half one GPU can run: 128x128 crops through the 32-64-128 | 128-64-32-1 instance of the layer
+    grammar (CAE_improved_modeltrain.py:184: input_shape is an argument) -- autoencoder forward + per-cell MSE / MAE on crops resident
+    in HBM, and batch-32 training steps (forward with batch statistics, backward, Adam) of the run-time-shaped trainer."""
+    import torch
+    from cellscreen import synth
+    from cellscreen.engine import Engine
+    from cellscreen.trainer import Trainer
+    hw, ch = (128, 128), (32, 64, 128, 128, 64, 32, 1)
+    macs = 349.18e6                                         # SURVEY.md Appendix A.2
+    dev = torch.device("cuda", local_rank)
+    w = synth.random_cae(seed=seed + 3, hw=hw, channels=ch, n_enc=3)
+    e = Engine.from_weights(w, device_id=local_rank)
+    try:
+        x = torch.rand((n,) + hw, dtype=torch.float32, device=dev)
+        e.set_chunk(4096)
+        e.reconstruct(x, want_recon=False)
+        torch.cuda.synchronize()
+        e.profile_enable(True); e.profile_reset()
+        steps = 3
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.reconstruct(x, want_recon=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        e.profile_enable(False)
+        kern = {}
+        for k, v in e.profile().items():
+            if not v["launches"]:
+                continue
+            r = dict(ms_per_step=round(v["ms"] / steps, 3))
+            if v.get("bf16_mfma_per_cell", 0) > 0:
+                tf = v["bf16_mfma_per_cell"] * FLOP_PER_BF16_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12
+                r.update(mfma16_per_cell=v["bf16_mfma_per_cell"], tflops_executed_16bit=round(tf, 1), frac_bf16_mfma_peak=round(tf / BF16_MFMA_PEAK_TFLOPS, 4))
+            elif v["mfma_per_cell"] > 0:
+                tf = v["mfma_per_cell"] * FLOP_PER_MFMA * v["cells"] / (v["ms"] * 1e-3) / 1e12
+                r.update(mfma_per_cell=v["mfma_per_cell"], tflops_executed=round(tf, 2), frac_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
+            kern[k] = r
+        del x
+    finally:
+        e.close()
+    torch.cuda.empty_cache()
+    fwd = dict(crops=n, cells_per_s=round(n / dt, 1), ms_per_step=round(dt * 1e3, 3), steps=steps, precision="split16",
+               tflops_algorithmic=round(2 * macs * n / dt / 1e12, 2), kernels=kern)
+    X = torch.from_numpy(synth.blob_crops(seed, 1024, hw=hw)).to(dev)
+    tr = Trainer(synth.random_cae(seed=seed, hw=hw, channels=ch, n_enc=3, trivial_bn=True), device_id=local_rank)
+    gen = torch.Generator(device=dev); gen.manual_seed(99)
+    try:
+        idx = torch.randint(0, len(X), (train_steps + 20, 32), device=dev, generator=gen)
+        first = None
+        for i in range(20):
+            xb = X[idx[i]].contiguous()
+            l, _ = tr.step(xb, xb, 1e-3)
+            first = l if first is None else first
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.reset_metrics()
+        for i in range(20, 20 + train_steps):
+            xb = X[idx[i]].contiguous()
+            tr.step_async(xb, xb, 1e-3)
+        loss_mean, _, _ = tr.read_metrics()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0) / train_steps
+    finally:
+        tr.close()
+    train = dict(steps=train_steps, batch=32, ms_per_step=round(dtt * 1e3, 4), cells_per_s=round(32 / dtt, 1),
+                 tflops_algorithmic=round(32 / dtt * 3 * 2 * macs / 1e12, 2), frac_fp32_mfma_peak_algorithmic=round(32 / dtt * 3 * 2 * macs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                 loss_first_step=round(first, 6), loss_mean=round(loss_mean, 6))
+    return dict(workload="BASELINE.json configs[4] on one GPU: 128x128 crops, deeper CAE (filters 32-64-128 | 128-64-32-1, 128-channel bottleneck, "
+                         "349.18 M MAC/cell), run-time-shaped MFMA implicit-GEMM kernels; the 8-GPU gradient all-reduce half is bench_train.py --variant under torchrun",
+                forward=fwd, train=train)
 
 
 def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
@@ -679,9 +809,11 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        oracle_ref = None
         if world == 1 and not args.no_cpu_baseline and not args.pmc_child:
             cb, ref_seq = cpu_reference_sequence(weights, sk, args.seed)
             port, ref, xs = cpu_port(weights, det, args.seed, args.cpu_sample)
+            oracle_ref = ref
             cb["port"] = port
             line["cpu_baseline"] = cb
             # the bounded samples double as live parity checks of the benchmarked run
@@ -704,7 +836,13 @@ def main():
             except Exception as e:  # noqa: BLE001 - an extra leg never costs the headline line
                 line["small_n"] = {"error": repr(e)}
             try:
-                line["exact_fp32"] = exact_fp32_leg(weights, det, x, out, args, local_rank)
+                line["exact_fp32"], head = exact_fp32_leg(weights, det, x, out, host, args, local_rank)
+                if oracle_ref is not None:          # the exact mode's own live parity check, same sample and bars as the headline's
+                    n = len(oracle_ref["mse"])
+                    rel = float(np.max(np.abs(head["mse"][:n] - oracle_ref["mse"]) / oracle_ref["mse"]))
+                    derr = float(np.max(np.abs(head["cons_score"][:n] - oracle_ref["cons_score"])))
+                    tol = 1e-4 * float(np.abs(det.conservative.dual_coef).sum())
+                    line["exact_fp32"]["parity_on_cpu_sample"] = {"cells": n, "mse_max_rel": rel, "cons_score_max_abs": derr, "ok": bool(rel <= 1e-5 and derr <= tol)}
             except Exception as e:  # noqa: BLE001
                 line["exact_fp32"] = {"error": repr(e)}
             del x
@@ -718,6 +856,11 @@ def main():
                 line["train_leg"] = train_leg(args.train_steps, local_rank, args.seed)
             except Exception as e:  # noqa: BLE001
                 line["train_leg"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                line["large_variant"] = large_variant_leg(local_rank, args.seed)
+            except Exception as e:  # noqa: BLE001
+                line["large_variant"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,6 +25,12 @@ def test_reference_sequence_counterpart_matches_the_oracle():
     assert cb["kind"] in ("counterpart", "reference") and cb["unit"] == "cells/s" and cb["value"] > 0
     assert set(cb["sizes"]) == {"32", "96"} and set(cb["sizes"]["96"]["split_ms"]) == {
         "autoencoder_predict_and_errors", "encoder_predict", "scaler_pca", "svm_4_calls"}
+    # the intra-op thread count is swept and the value is quoted at the best one (128 threads on 32-image batches
+    # was oversubscription, not a baseline)
+    sw = cb["thread_sweep"]["96"]
+    assert cb["cores"] == sw["best_threads"] == cb["sizes"]["96"]["torch_threads"] and len(sw["cells_per_s_by_threads"]) >= 2
+    assert sw["cells_per_s_by_threads"][str(sw["best_threads"])] == max(sw["cells_per_s_by_threads"].values())
+    assert cb["host_cpus_in_affinity_mask"] >= 1
     ref = oracle.screen(w, None, det, oracle.synth_crops(42, 0, 96), acc64=True)
     assert np.max(np.abs(last["mse"] - ref["mse"]) / ref["mse"]) <= 1e-5
     assert np.max(np.abs(last["mae"] - ref["mae"]) / ref["mae"]) <= 1e-5
