@@ -42,11 +42,14 @@ namespace {
 constexpr int NTHR = 512;
 constexpr int V_BYTES = 36 * 2048;                   // [xi][q][kq][slot][4]: 2 KB per transform point
 constexpr int RING_SLOTS = 10;
-constexpr int RING_ROWF = 34 * 32;                   // floats per slot: 32 interior columns + 2 halo, 32 channels
+constexpr int RING_ROWF = 34 * 32 + 8;               // floats per slot: 32 interior columns + 2 halo, 32 channels, + 8: four rows down is
+                                                     // 32 banks on (P2's ds_read_b64 groups hold one tile of each tile row)
+static_assert((4 * RING_ROWF) % 64 == 32 && RING_ROWF % 2 == 0, "ring pitch");
 constexpr int RING_BYTES = RING_SLOTS * RING_ROWF * 4;
 constexpr int E2_BYTES = 8 * 2048;
 constexpr int INP_STRIDE = 72;                       // floats per crop row: interior at 4..67 (16-byte aligned), halo at 3 and 68
-constexpr int INP_BYTES = 66 * INP_STRIDE * 4;
+constexpr int INP_BYTES = 67 * INP_STRIDE * 4;         // crop rows -1 .. 64, + one zero row: P1's K = 32 fragments read one record row past
+                                                     // their window (against zero weights: it has to be finite)
 constexpr int OFF_RING = V_BYTES;
 constexpr int OFF_E2 = OFF_RING + RING_BYTES;
 constexpr int OFF_INP = OFF_E2 + E2_BYTES;
@@ -57,8 +60,6 @@ constexpr int OFF_B1X = OFF_EP2 + 64 * 16;             // conv1 on bf16 MFMAs: B
 constexpr int OFF_W9 = OFF_B1X + 2 * 3 * 64 * 16;      // ... and the fp32 weight of tap (2,2) per channel
 constexpr int OFF_XMAX = OFF_W9 + 32 * 4;               // C2H: max|x| of the crop staged for the next cell (one word; 16 bytes kept)
 constexpr int LDS_BYTES = OFF_XMAX + 16;
-constexpr int REC_ROWS = 20;                           // crop rows of a group as bf16 records, kept in the (then dead) V area
-static_assert(REC_ROWS * INP_STRIDE * 8 <= V_BYTES, "records live in the V area");
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_RING % 16 == 0 && OFF_E2 % 16 == 0 && OFF_INP % 16 == 0, "LDS map");
 
 __device__ __forceinline__ float vmaxf(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -86,7 +87,9 @@ __device__ __forceinline__ void mfma_result_fence(f32x4 (&a)[4], f32x4 (&b)[4])
 // window's min is -max(-z), and v = sgn * max + bias with sgn = -1 for those channels -- one fma, no second path.
 __device__ __forceinline__ float pool_post(float a, float b, float c, float d, float sgn, float bias, float bns, float bnt)
 {
-    const float mx = vmaxf(vmaxf(a, b), vmaxf(c, d));
+    float mx;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(a), "v"(b), "v"(c));       // raw, like vmaxf: see mfma_result_fence
+    mx = vmaxf(mx, d);
     const float v = vmaxf(fmaf(sgn, mx, bias), 0.0f);   // raw v_max: never NaN for finite inputs, no canonicalisation needed
     return fmaf(v, bns, bnt);
 }
@@ -154,6 +157,73 @@ __device__ __forceinline__ void c12_sanitize(f32x4& v)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = __builtin_fabsf(v[j]) <= 3.402823466e38f ? v[j] : 0.0f;
+}
+
+// one ds_read_b64 that the load / store optimiser leaves alone (a volatile access in the LDS address space)
+__device__ __forceinline__ f32x2 lds_read_b64(const float* p)
+{
+    typedef const volatile __attribute__((address_space(3))) f32x2* lds_ptr;
+    return *(lds_ptr)p;
+}
+__device__ __forceinline__ f32x2 pfma(float c, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{c, c}, a, b); }
+
+// B^T of F(4,3) on a channel pair, the rows a thread of P2 owns: LO = outputs (0, 1, 2) from inputs d0 .. d4, otherwise outputs
+// (3, 4, 5) from d1 .. d5 (d[] holds the five inputs in order).  The operations and their order are bt6's.
+template <bool LO>
+__device__ __forceinline__ void bt6_half(const f32x2 (&d)[5], f32x2 (&o)[3])
+{
+    if constexpr (LO) {
+        o[0] = pfma(4.0f, d[0], pfma(-5.0f, d[2], d[4]));
+        const f32x2 t1 = pfma(-4.0f, d[2], d[4]), t2 = pfma(-4.0f, d[1], d[3]);
+        o[1] = t1 + t2;
+        o[2] = t1 - t2;
+    } else {
+        const f32x2 t3 = d[3] - d[1], t4 = d[2] - d[0];
+        o[0] = pfma(2.0f, t4, t3);
+        o[1] = pfma(-2.0f, t4, t3);
+        o[2] = pfma(4.0f, d[0], pfma(-5.0f, d[2], d[4]));
+    }
+}
+__device__ __forceinline__ void bt6_pair(const f32x2 (&d)[6], f32x2 (&o)[6])
+{
+    o[0] = pfma(4.0f, d[0], pfma(-5.0f, d[2], d[4]));
+    o[5] = pfma(4.0f, d[1], pfma(-5.0f, d[3], d[5]));
+    const f32x2 t1 = pfma(-4.0f, d[2], d[4]), t2 = pfma(-4.0f, d[1], d[3]);
+    o[1] = t1 + t2;
+    o[2] = t1 - t2;
+    const f32x2 t3 = d[4] - d[2], t4 = d[3] - d[1];
+    o[3] = pfma(2.0f, t4, t3);
+    o[4] = pfma(-2.0f, t4, t3);
+}
+// Six channel pairs -> [hi c | hi c+1] and [lo c | lo c+1] dwords (hi = fp16(v), lo = fp16(v - hi)): one v_cvt_pk_f16_f32 and two
+// v_fma_mix per pair, no lane exchange.  Both hi are fp16 of the fp32 value the transform stored (see P2's comment on the fold).
+__device__ __forceinline__ void f16x2_split6_pairs(const f32x2 (&v)[6], unsigned int (&hi)[6], unsigned int (&lo)[6])
+{
+    float a[6], b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { a[c] = v[c][0]; b[c] = v[c][1]; }
+    asm("v_cvt_pk_f16_f32 %0, %12, %18\n\t"
+        "v_cvt_pk_f16_f32 %1, %13, %19\n\t"
+        "v_cvt_pk_f16_f32 %2, %14, %20\n\t"
+        "v_cvt_pk_f16_f32 %3, %15, %21\n\t"
+        "v_cvt_pk_f16_f32 %4, %16, %22\n\t"
+        "v_cvt_pk_f16_f32 %5, %17, %23\n\t"
+        "v_fma_mixlo_f16 %6, %12, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %13, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %8, %14, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %9, %15, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %10, %16, 1.0, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %11, %17, 1.0, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %18, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %19, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %8, %20, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %9, %21, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %10, %22, 1.0, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %11, %23, 1.0, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]),
+          "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]));
 }
 
 // C2H: conv2's contraction M = V U (P3) as a TWO-term fp16 split on v_mfma_f32_16x16x32_f16 (conv_wino_up.hip, conv67_h2_kernel, has
@@ -261,25 +331,22 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
         vunscale = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23) * inv_sw;
     };
     if constexpr (C2H) set_scale();
-    // records of group gn's crop rows (INP rows row0 .. row0 + rows - 1: conv rows 16 gn + 2 .. 16 gn + 17 and their halo; group 0
-    // also conv rows 0, 1; the last group stops at the bottom halo row)
-    auto build_records = [&](int gn, int t) {
-        const int row0 = gn == 0 ? 0 : 16 * gn + 2;
-        const int nrec = (gn == 0 ? REC_ROWS : (gn == 3 ? 16 : 18)) * INP_STRIDE;
-        // 1,152 .. 1,440 records: two per thread and a third for some; all reads first (one LDS latency instead of three)
-        const float* src = inp + row0 * INP_STRIDE;
-        const float v0 = src[t], v1 = src[t + NTHR], v2 = src[t + 2 * NTHR < nrec ? t + 2 * NTHR : t];
-        if constexpr (C1H) {       // one dword per pixel: [fp16(S x) | fp16(S x - hi)]
-            auto rec = [&](float x) {
-                return f16x2_split_word_scaled(x, xscale);
-            };
-            *(unsigned int*)(smem + t * 4) = rec(v0);
-            *(unsigned int*)(smem + (t + NTHR) * 4) = rec(v1);
-            if (t + 2 * NTHR < nrec) *(unsigned int*)(smem + (t + 2 * NTHR) * 4) = rec(v2);
-        }
+    // C1H: conv1 reads the crop as one-dword records [fp16(S_x x) | fp16(S_x x - hi)].  The crop is staged as fp32 (its maximum fixes
+    // S_x), then every thread turns the eight values it staged itself into records IN PLACE (same four bytes, no other thread's
+    // data: no barrier of its own); the zero halo is the zero record.  INP then holds the whole cell's records until the next crop
+    // replaces it, so P1 addresses them by crop row and nothing has to be rebuilt per group.
+    auto records_in_place = [&](int t) {
+        float* p0 = inp + ((t >> 4) + 1) * INP_STRIDE + 4 + 4 * (t & 15);
+        float* p1 = p0 + 32 * INP_STRIDE;
+        const f32x4 a = *(const f32x4*)p0, b = *(const f32x4*)p1;
+        const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        *(u32x4*)p0 = u32x4{f16x2_split_word_scaled(a0, xscale), f16x2_split_word_scaled(a1, xscale), f16x2_split_word_scaled(a2, xscale),
+                            f16x2_split_word_scaled(a3, xscale)};
+        *(u32x4*)p1 = u32x4{f16x2_split_word_scaled(b0, xscale), f16x2_split_word_scaled(b1, xscale), f16x2_split_word_scaled(b2, xscale),
+                            f16x2_split_word_scaled(b3, xscale)};
     };
-    if constexpr (C1X3) {
-        build_records(0, tid);
+    if constexpr (C1H) {
+        records_in_place(tid);
         __syncthreads();
     }
 
@@ -319,9 +386,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 e1v[1] *= vscale; e1v[2] *= vscale;                                     // the ring holds S p1
                 e1v[3] *= xunscale;                                                     // the sums carry S_x S_w1
                 const int pwoff = (8 * xt + 2 * kq2 + 1) * 32 + c1;
-                const int row0 = g == 0 ? 0 : 16 * g + 2;                                // first INP row of this group's records
                 auto frag = [&](int inp_row) -> f16x8 {
-                    const unsigned int* b = (const unsigned int*)(smem + (inp_row - row0) * (INP_STRIDE * 4) + offR);
+                    const unsigned int* b = (const unsigned int*)(smem + OFF_INP + inp_row * (INP_STRIDE * 4) + offR);
                     return __builtin_bit_cast(f16x8, u32x4{b[0], b[1], b[INP_STRIDE], b[INP_STRIDE + 1]});
                 };
                 auto conv_row = [&](const f16x8& a) -> f32x4 {
@@ -437,8 +503,83 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             __syncthreads();
             C12_STAMP(1)
 
-            // ================= P2: V = B^T d B of this thread's (tile, channel) patch
-            {
+            // ================= P2: V = B^T d B
+            if constexpr (C2H) {
+                // A thread owns a channel PAIR of one tile and HALF of the transform rows: wave w = (row half h = w & 1, tile columns
+                // 2 (w >> 1) + {0, 1}), lane = (pair p, tile row, tile column).  The pair is one ds_read_b64 and one packed-fp32
+                // operation per step of the transform (v_pk_fma_f32 / v_pk_add_f32: both channels at once), its hi and lo dwords
+                // [hi c | hi c+1], [lo c | lo c+1] are one v_cvt_pk_f16_f32 + two v_fma_mix with no lane exchange, and the rows of B^T d
+                // split 3 | 3 without redundant work (outputs 0-2 need input rows 0-4, outputs 3-5 rows 1-5): 72 packed + 54 split
+                // instructions per thread where the (tile, channel) form spent 144 + 144.
+                // LDS: a ds_read_b64 is served 32 lanes at a time over 64 banks: lanes 0-15 read one tile's 16 pairs (32 consecutive
+                // dwords), lanes 16-31 the tile four ring rows below -- 4 RING_ROWF = 32 banks on.  The ds_write_b32 groups (32
+                // lanes, 32 banks) hold the same two tiles: their slots differ by the XOR's bit 2, so the 32 dwords are distinct.
+                const int h = w & 1, p = l2 & 15, trow = (l2 >> 4) & 1, tx = 2 * (w >> 1) + (l2 >> 5), tile = 8 * trow + tx;
+                // ring rows 4 trow + h + m, m = 0..4 -> slots (8 g + row) mod 10 (one conditional subtraction: the sum stays below 20)
+                const int rbase = (8 * g) % RING_SLOTS + 4 * trow + h;
+                const float* const rcol = ring + (4 * tx) * 32 + 2 * p;
+                // the two halves are two instantiations of the body (h is wave-uniform: one scalar branch per phase)
+                auto p2_body = [&](auto lo_c) {
+                    constexpr bool LO = decltype(lo_c)::value;
+                    f32x2 t[3][6];
+                    {
+                        const float* rrow[5];
+    #pragma unroll
+                        for (int m = 0; m < 5; ++m) {
+                            const unsigned int sm = (unsigned int)(rbase + m);
+                            const unsigned int slot = min(sm, sm - (unsigned int)RING_SLOTS);       // unsigned wrap: sm - 10 is huge below 10
+                            rrow[m] = rcol + slot * RING_ROWF;
+                        }
+                        // reads column by column (a column's five rows feed its B^T d at once, so the transform starts while the later
+                        // columns are still in flight); volatile keeps them single ds_read_b64 -- merged into ds_read2_b64 they are
+                        // served 16 lanes at a time over 32 banks, at half the rate
+                        f32x2 d[6][5];
+    #pragma unroll
+                        for (int j = 0; j < 6; ++j)
+    #pragma unroll
+                            for (int m = 0; m < 5; ++m) d[j][m] = lds_read_b64(rrow[m] + j * 32);
+                        if (g == 3 && has_next) {   // the crop buffer is dead since the barrier above
+                            float* dst = inp + ((t2 >> 4) + 1) * INP_STRIDE + 4 + 4 * (t2 & 15);
+                            c12_sanitize(stg0);
+                            c12_sanitize(stg1);
+                            *(f32x4*)dst = stg0;
+                            *(f32x4*)(dst + 32 * INP_STRIDE) = stg1;
+                            const unsigned int mx = c12_rowmax(c12_absmax8(stg0, stg1));
+                            if ((l2 & 15) == 0) atomicMax((unsigned int*)(smem + OFF_XMAX), mx);
+                        }
+                        // rows first (B^T d): this thread's three rows of every column
+    #pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            f32x2 o[3];
+                            bt6_half<LO>(d[j], o);
+    #pragma unroll
+                            for (int rr = 0; rr < 3; ++rr) t[rr][j] = o[rr];
+                        }
+                    }
+                    // then columns ((B^T d) B), split, store: [point][tile][slot ^ ((tile >> 1) & 7)][16 B], slots 0-3 = hi of channels
+                    // 8 kq .., 4-7 = lo: the pair's hi dword goes to slot p >> 2, its lo dword to slot 4 + (p >> 2) (the XOR's bit 2)
+                    const int sx = (tile >> 1) & 7;
+                    char* const vhi = smem + (3 * h) * (6 * 2048) + (tile * 8 + ((p >> 2) ^ sx)) * 16 + (p & 3) * 4;
+                    char* const vlo = smem + (3 * h) * (6 * 2048) + (tile * 8 + ((4 + (p >> 2)) ^ sx)) * 16 + (p & 3) * 4;
+    #pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        f32x2 o[6];
+                        bt6_pair(t[rr], o);
+                        // both hi are fp16 of the SAME fp32 value: left to the compiler, the transform's last fma was folded into one of
+                        // the conversions (v_fma_mixlo_f16: one rounding of the exact sum) and the residual taken against the wrong hi
+                        unsigned int ph[6], pl[6];
+                        f16x2_split6_pairs(o, ph, pl);
+    #pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            *(unsigned int*)(vhi + (rr * 6 + c) * 2048) = ph[c];
+                            *(unsigned int*)(vlo + (rr * 6 + c) * 2048) = pl[c];
+                        }
+                    }
+                };
+                if (h == 0) p2_body(std::true_type{});
+                else p2_body(std::false_type{});
+            } else {
+                // thread (tile, channel): scalar LDS reads, conflict-free (a half wave reads 32 consecutive channels)
                 const int tile = t2 >> 5, ch = t2 & 31, trow = w >> 2, tx = tile & 7;
                 const int roff = (4 * tx) * 32 + ch;                              // first patch column of the tile, this channel
                 const int vq = ch >> 4, vkq = (ch >> 2) & 3, vj = ch & 3;
@@ -460,10 +601,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     c12_sanitize(stg1);
                     *(f32x4*)dst = stg0;
                     *(f32x4*)(dst + 32 * INP_STRIDE) = stg1;
-                    if constexpr (C2H) {
-                        const unsigned int mx = c12_rowmax(c12_absmax8(stg0, stg1));
-                        if ((l2 & 15) == 0) atomicMax((unsigned int*)(smem + OFF_XMAX), mx);
-                    }
                 }
                 // rows first (B^T d), then columns ((B^T d) B): V[r][c]
                 float t[6][6];
@@ -476,33 +613,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 #pragma unroll
                     for (int i = 0; i < 6; ++i) t[i][j] = o[i];
                 }
-                if constexpr (C2H) {
-                    // [point][tile][slot ^ ((tile >> 1) & 7)][16 B]: this thread's dword = channel pair ch >> 1 of plane ch & 1
-                    const int pl = ch & 1, pair = ch >> 1;
-                    const int hoff = (tile * 8 + ((pl * 4 + (pair >> 2)) ^ ((tile >> 1) & 7))) * 16 + (pair & 3) * 4;
-                    const unsigned int sel = pl ? 0x03020706u : 0x05040100u;    // odd lane: [lo c-1 | lo c], even lane: [hi c | hi c+1]
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        float o[6];
-                        bt6(t[r], o);
-                        // [hi | lo] of each value (hi = fp16(v), lo = fp16(v - hi): one v_cvt + one v_fma_mixhi_f16), the dword of
-                        // lane ^ 1 by DPP, one v_perm_b32: 4 VALU per value, six chains interleaved (common.hpp).  Both hi are
-                        // fp16 of the SAME fp32 v -- left to the compiler, the transform's last fma was folded into one of the
-                        // two conversions (v_fma_mixlo_f16: one rounding of the exact sum) and the residual was taken against the
-                        // wrong hi (2^-10 errors in p2).
-                        unsigned int pk[6];
-                        f16x2_split6_exchange(o, sel, pk);
+                for (int r = 0; r < 6; ++r) {
+                    float o[6];
+                    bt6(t[r], o);
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) *(unsigned int*)(smem + (r * 6 + c) * 2048 + hoff) = pk[c];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        float o[6];
-                        bt6(t[r], o);
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) *(float*)(smem + (r * 6 + c) * 2048 + voff) = o[c];
-                    }
+                    for (int c = 0; c < 6; ++c) *(float*)(smem + (r * 6 + c) * 2048 + voff) = o[c];
                 }
             }
             C12_STAMP(2)
@@ -510,6 +626,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             C12_STAMP(3)
 
             // ================= P3: M = V U on the matrix pipe, row fold in registers
+#ifdef CS_X_STG3
+            if (w >= 4) __builtin_amdgcn_s_sleep(CS_X_STG3);
+#endif
             f32x4 own[3][2];
             {
                 // A operand slots of lane (tile li, channel quad kq) for q = 0, 1
@@ -529,11 +648,21 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             const int xi = (r0 + t) * 6 + 3 * gcol + cc;
+#ifdef CS_X_NOLDS
+                            ah[t] = __builtin_bit_cast(f16x8, f32x4{U[xi], U[xi + 1], U[xi + 2], U[xi + 3]});
+                            al[t] = __builtin_bit_cast(f16x8, f32x4{U[xi + 4], U[xi + 5], U[xi + 6], U[xi + 7]});
+#else
                             ah[t] = *(const f16x8*)(smem + xi * 2048 + hoffh);
                             al[t] = *(const f16x8*)(smem + xi * 2048 + hoffl);
+#endif
                         }
                         auto Uh = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8], U[pt * 8 + 1], U[pt * 8 + 2], U[pt * 8 + 3]}); };
                         auto Ul = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8 + 4], U[pt * 8 + 5], U[pt * 8 + 6], U[pt * 8 + 7]}); };
+#ifdef CS_X_NOMFMA
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) m[t] = __builtin_bit_cast(f32x4, ah[t]) + __builtin_bit_cast(f32x4, al[t]) + f32x4{U[cc * 6 + r0 + t], 0.0f, 0.0f, 0.0f};
+                        return;
+#endif
 #pragma unroll
                         for (int t = 0; t < 3; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], Ul(cc * 6 + r0 + t), f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
 #pragma unroll
@@ -564,10 +693,24 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     //             s3 = (m1-m2) + 8 (m3-m4) + m5
                     f32x4 ma[3], mb[3];
                     trio(cc, 0, ma);
+#ifdef CS_X_NOFOLD
+                    trio(cc, 3, mb);
+                    const f32x4 s0 = ma[0], s1 = ma[1] + ma[2], s2 = mb[0], s3 = mb[1] + mb[2];
+#elif defined(CS_X_SCALAR_FOLD)
+                    trio(cc, 3, mb);
+                    f32x4 s0, s1, s2, s3;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a0 = ma[0][r], a1 = ma[1][r], a2 = ma[2][r], b0 = mb[0][r], b1 = mb[1][r], b2 = mb[2][r];
+                        const float p = a1 + a2, mq = a1 - a2, u = b0 + b1, v = b0 - b1;
+                        s0[r] = a0 + p + u; s1[r] = fmaf(2.0f, v, mq); s2[r] = fmaf(4.0f, u, p); s3[r] = fmaf(8.0f, v, mq) + b2;
+                    }
+#else
                     const f32x4 p = ma[1] + ma[2], mq = ma[1] - ma[2];
                     trio(cc, 3, mb);
                     const f32x4 u = mb[0] + mb[1], v = mb[0] - mb[1];
                     const f32x4 s0 = ma[0] + p + u, s1 = mq + 2.0f * v, s2 = p + 4.0f * u, s3 = mq + 8.0f * v + mb[2];
+#endif
                     // rows (2 gcol, 2 gcol + 1) stay, the other two go to the partner wave.  The asm statements keep the
                     // compiler from turning this wave-uniform branch into 16 v_cndmask per column.
                     f32x4 ta, tb;
@@ -625,8 +768,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 if constexpr (C2H) {
                     if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2 (this group's sums are out)
                 }
-                if constexpr (C1X3) {      // V is dead until the next P2: the next group's records (g = 3: the next cell's crop is in place since P2)
-                    if (g < 3 || has_next) build_records(g < 3 ? g + 1 : 0, t2);
+                if constexpr (C1H) {
+                    if (g == 3 && has_next) records_in_place(t2);     // the next cell's crop (this thread's own eight values, staged in P2)
                 }
             }
             C12_STAMP(6)
