@@ -17,8 +17,6 @@ HEADERS = ["common.hpp", "api_internal.hpp", "train_internal.hpp", "tensor_archi
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]
-# per-file additions (measured): none by default
-EXTRA_FLAGS = {"conv12_fused.hip": os.environ.get("CS_BUILD_C12_FLAGS", "").split()}
 
 
 def source_hash():
@@ -50,7 +48,7 @@ def build(force=False, keep_temps=False, verbose=True):
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not _newer(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if keep_temps:
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             jobs.append(cmd)

@@ -626,9 +626,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             C12_STAMP(3)
 
             // ================= P3: M = V U on the matrix pipe, row fold in registers
-#ifdef CS_X_STG3
-            if (w >= 4) __builtin_amdgcn_s_sleep(CS_X_STG3);
-#endif
             f32x4 own[3][2];
             {
                 // A operand slots of lane (tile li, channel quad kq) for q = 0, 1
@@ -648,21 +645,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             const int xi = (r0 + t) * 6 + 3 * gcol + cc;
-#ifdef CS_X_NOLDS
-                            ah[t] = __builtin_bit_cast(f16x8, f32x4{U[xi], U[xi + 1], U[xi + 2], U[xi + 3]});
-                            al[t] = __builtin_bit_cast(f16x8, f32x4{U[xi + 4], U[xi + 5], U[xi + 6], U[xi + 7]});
-#else
                             ah[t] = *(const f16x8*)(smem + xi * 2048 + hoffh);
                             al[t] = *(const f16x8*)(smem + xi * 2048 + hoffl);
-#endif
                         }
                         auto Uh = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8], U[pt * 8 + 1], U[pt * 8 + 2], U[pt * 8 + 3]}); };
                         auto Ul = [&](int pt) { return __builtin_bit_cast(f16x8, f32x4{U[pt * 8 + 4], U[pt * 8 + 5], U[pt * 8 + 6], U[pt * 8 + 7]}); };
-#ifdef CS_X_NOMFMA
-#pragma unroll
-                        for (int t = 0; t < 3; ++t) m[t] = __builtin_bit_cast(f32x4, ah[t]) + __builtin_bit_cast(f32x4, al[t]) + f32x4{U[cc * 6 + r0 + t], 0.0f, 0.0f, 0.0f};
-                        return;
-#endif
 #pragma unroll
                         for (int t = 0; t < 3; ++t) m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], Ul(cc * 6 + r0 + t), f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
 #pragma unroll
@@ -693,24 +680,10 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     //             s3 = (m1-m2) + 8 (m3-m4) + m5
                     f32x4 ma[3], mb[3];
                     trio(cc, 0, ma);
-#ifdef CS_X_NOFOLD
-                    trio(cc, 3, mb);
-                    const f32x4 s0 = ma[0], s1 = ma[1] + ma[2], s2 = mb[0], s3 = mb[1] + mb[2];
-#elif defined(CS_X_SCALAR_FOLD)
-                    trio(cc, 3, mb);
-                    f32x4 s0, s1, s2, s3;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a0 = ma[0][r], a1 = ma[1][r], a2 = ma[2][r], b0 = mb[0][r], b1 = mb[1][r], b2 = mb[2][r];
-                        const float p = a1 + a2, mq = a1 - a2, u = b0 + b1, v = b0 - b1;
-                        s0[r] = a0 + p + u; s1[r] = fmaf(2.0f, v, mq); s2[r] = fmaf(4.0f, u, p); s3[r] = fmaf(8.0f, v, mq) + b2;
-                    }
-#else
                     const f32x4 p = ma[1] + ma[2], mq = ma[1] - ma[2];
                     trio(cc, 3, mb);
                     const f32x4 u = mb[0] + mb[1], v = mb[0] - mb[1];
                     const f32x4 s0 = ma[0] + p + u, s1 = mq + 2.0f * v, s2 = p + 4.0f * u, s3 = mq + 8.0f * v + mb[2];
-#endif
                     // rows (2 gcol, 2 gcol + 1) stay, the other two go to the partner wave.  The asm statements keep the
                     // compiler from turning this wave-uniform branch into 16 v_cndmask per column.
                     f32x4 ta, tb;

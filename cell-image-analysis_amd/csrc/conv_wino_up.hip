@@ -23,6 +23,8 @@
 // transform, so only nine accumulators are live at a time.
 #include "common.hpp"
 
+#include <type_traits>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -737,7 +739,10 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
             *(f32x4*)&wc[0] = *(const f32x4*)(wl + li * 36 + kq * 8);
             *(f32x4*)&wc[4] = *(const f32x4*)(wl + li * 36 + kq * 8 + 4);
             {
-                const float* ap = a6s + ((wave * 32 + li) * F67::PA + kq * 8);
+                // A row i of the contraction is pixel 4 (i & 3) + (i >> 2) of the 16: D then has pixel 4 r + kq in register r of lane
+                // (n = li, kq), and a ds_write_b32 of one r puts kq = 0 / 1 on neighbouring floats -- with pixel 4 kq + r the lanes
+                // (li, kq), (li - 1, kq + 1), (li + 8, kq), (li + 7, kq + 1) met on one bank (4-way: 3,800 conflict cycles per cell)
+                const float* ap = a6s + ((wave * 32 + 4 * (li & 3) + (li >> 2)) * F67::PA + kq * 8);
                 const f32x4 a00 = *(const f32x4*)ap, a01 = *(const f32x4*)(ap + 4);
                 const f32x4 a10 = *(const f32x4*)(ap + 16 * F67::PA), a11 = *(const f32x4*)(ap + 16 * F67::PA + 4);
                 f32x4 t0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;                     // two independent chains, interleaved
@@ -751,9 +756,9 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
                     t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
                     t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
                 }
-                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67H::TW + 4 * kq + 1;
+                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67H::TW + kq + 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { tw[r] = t0[r]; tw[16 + r] = t1[r]; }
+                for (int r = 0; r < 4; ++r) { tw[4 * r] = t0[r]; tw[16 + 4 * r] = t1[r]; }
             }
             if (has_next) {      // every wave is past the first barrier: nobody reads the current strip any more, and the word holds the maximum
                 float S, invS;
@@ -973,6 +978,7 @@ hipError_t launch_conv67_h2(const float* a5, const uint16_t* wplanes, float inv_
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)conv67_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F67H::LDS);
         if (e != hipSuccess) return e;
+
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
