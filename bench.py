@@ -341,9 +341,10 @@ def _cpu_model():
 def train_leg(steps, local_rank, seed):
     """BASELINE.json configs[1] as written (CAE_improved_modeltrain.py:240,246-254,286-293): 50,000 synthetic crops split
     40,000 / 10,000, resident in HBM; one epoch = 1,250 fit() batches of 32 -- shuffled gather, the reference's
-    ImageDataGenerator augmentation on the INPUT only (cs_train_augment on the device), forward + backward + Adam -- then the
-    validation pass over the 10,000 held-out crops.  Nothing synchronises the host inside the epoch: the per-step loss / MAE
-    stay on the device and are read once at the end (cs_train_read_metrics)."""
+    ImageDataGenerator augmentation on the INPUT only, forward + backward + Adam, each batch ONE library call (cs_train_fit_step: the
+    transforms are drawn in C from a keyed generator, the batch is gathered by the resampling kernel) -- then the validation pass
+    over the 10,000 held-out crops.  Nothing synchronises the host inside the epoch: the per-step loss / MAE stay on the device
+    and are read once at the end (cs_train_read_metrics)."""
     import numpy as np
     import torch
     from cellscreen import synth
@@ -369,12 +370,15 @@ def train_leg(steps, local_rank, seed):
             l, _ = tr.step(tr.augment(yb, gen.random_transforms(32, (64, 64), rng)), yb, 1e-3)
             first = l if first is None else first
         torch.cuda.synchronize()
+        Xtr = Xtr.contiguous()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         perm = torch.randperm(len(Xtr), device=dev, generator=tg)[:steps * 32].view(steps, 32)       # one shuffled pass
         tr.reset_metrics()
-        for i in range(steps):
-            yb = Xtr[perm[i]].contiguous()                 # the wrapper orders the library's stream after torch's
-            tr.step_async(tr.augment(yb, gen.random_transforms(32, (64, 64), rng)), yb, 1e-3)
+        idx = perm.cpu().numpy().astype(np.int32)          # the epoch's shuffled order, on the host (32 x 4 bytes per step)
+        cfg = gen.config()
+        for i in range(steps):                             # ONE library call per fit() batch: gather, keyed augmentation draws, step
+            tr.fit_step(Xtr, idx[i], cfg, seed=seed, step=i, lr=1e-3)
         t_enq = time.perf_counter() - t0                   # when the host has enqueued the epoch (it runs ahead of the device, or bounds it)
         loss_epoch, mae_epoch, _ = tr.read_metrics()       # one host round trip for the epoch (Keras's running means)
         torch.cuda.synchronize()
@@ -382,11 +386,20 @@ def train_leg(steps, local_rank, seed):
         val_loss, val_mae = tr.evaluate(Xva, Xva) if full_epoch else (None, None)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        # what a step costs the HOST: a burst shorter than the ring of in-flight steps (16), so that nothing waits for the device
+        # (inside the epoch the host runs 16 steps ahead and then waits for slots: its loop time there is the device's)
+        nb = 12
+        tb = time.perf_counter()
+        for i in range(nb):
+            tr.fit_step(Xtr, idx[i % len(idx)], cfg, seed=seed + 1, step=i, lr=1e-3)
+        t_host = (time.perf_counter() - tb) / nb
+        torch.cuda.synchronize()
     finally:
         tr.close()
     return dict(workload="BASELINE.json configs[1]: CAE training (fwd + bwd + Adam, BN batch statistics, on-device augmentation of the input), "
                          "50,000 synthetic crops -> 40,000 / 10,000, batch 32, fp32, 1 GPU" + ("" if full_epoch else " (--train-steps: partial epoch, no validation pass)"),
-                steps=steps, ms_per_step=round(t_train / steps * 1e3, 4), host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 4), cells_per_s=round(steps * 32 / t_train, 1),
+                steps=steps, ms_per_step=round(t_train / steps * 1e3, 4), host_enqueue_ms_per_step=round(t_host * 1e3, 4),
+                host_loop_ms_per_step_in_epoch=round(t_enq / steps * 1e3, 4), host_calls_per_step=1, cells_per_s=round(steps * 32 / t_train, 1),
                 tflops_algorithmic=round(steps * 32 / t_train * 3 * FLOP_PER_CELL / 1e12, 3),
                 epoch_s=round(el, 3) if full_epoch else None, validation_s=round(el - t_train, 3) if full_epoch else None,
                 loss_first_step=round(first, 6), loss_epoch_mean=round(loss_epoch, 6), mae_epoch_mean=round(mae_epoch, 6),

@@ -26,6 +26,12 @@ class CSAugAffine(C.Structure):
                 ("flip_v", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CSAugConfig(C.Structure):
+    _fields_ = [("rotation_range", C.c_double), ("width_shift_range", C.c_double), ("height_shift_range", C.c_double),
+                ("zoom_lo", C.c_double), ("zoom_hi", C.c_double), ("horizontal_flip", C.c_int32), ("vertical_flip", C.c_int32),
+                ("center", C.c_double)]
+
+
 class CSCaeWeights(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_conv", C.c_int32), ("n_enc", C.c_int32),
                 ("channels", C.c_int32 * CS_MAX_CONV),
@@ -135,6 +141,8 @@ SIGNATURES = {
     "cs_train_step": (_I, [_P, _P, _P, _L, _I, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_step_async": (_I, [_P, _P, _P, _L, _I, C.c_float]),
     "cs_train_inputs_consumed": (_I, [_P, _P]),
+    "cs_train_draw_transforms": (_I, [C.POINTER(CSAugConfig), C.c_uint64, C.c_uint64, _L, C.c_int32, C.c_int32, _P]),
+    "cs_train_fit_step": (_I, [_P, _P, _L, _P, _L, C.POINTER(CSAugConfig), C.c_uint64, C.c_uint64, C.c_float]),
     "cs_train_read_metrics": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L), _I]),
     "cs_train_forward_backward": (_I, [_P, _P, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cs_train_apply": (_I, [_P, C.c_float]),

@@ -137,6 +137,44 @@ class ImageDataGenerator:
         out["flip_h"], out["flip_v"] = fh, fv
         return out
 
+    # ---- the keyed draws of cs_train_fit_step --------------------------------------------------------
+    def config(self) -> "L.CSAugConfig":
+        """This generator as the C ABI's cs_aug_config (cs_train_fit_step draws the transforms itself)."""
+        c = L.CSAugConfig()
+        c.rotation_range = self.rotation_range
+        c.width_shift_range, c.height_shift_range = self.width_shift_range, self.height_shift_range
+        c.zoom_lo, c.zoom_hi = self.zoom_range
+        c.horizontal_flip, c.vertical_flip = int(self.horizontal_flip), int(self.vertical_flip)
+        c.center = self.center
+        return c
+
+    def keyed_transforms(self, seed: int, step: int, n: int, img_shape) -> np.ndarray:
+        """The n transforms cs_train_fit_step draws for fit() step `step` (csrc/train_api.hip: fit_transform): image b's seven
+        uniforms are counter_uniforms(seed, step, n)[b] in Keras's get_random_transform order, reduced with random_transforms'
+        closed form.  Host mirror of the C function: tests hold the two together."""
+        h, w = float(img_shape[0]), float(img_shape[1])
+        u = counter_uniforms(seed, step, n)
+        lo_hi = lambda r, col: -r + (r - -r) * u[:, col]                               # noqa: E731  numpy's uniform(lo, hi): lo + (hi - lo) u
+        theta = (lo_hi(self.rotation_range, 0) if self.rotation_range else np.zeros(n)) * (np.pi / 180.0)
+        tx = lo_hi(self.height_shift_range, 1) * (h if self.height_shift_range < 1 else 1.0) if self.height_shift_range else np.zeros(n)
+        ty = lo_hi(self.width_shift_range, 2) * (w if self.width_shift_range < 1 else 1.0) if self.width_shift_range else np.zeros(n)
+        if self.zoom_range[0] == 1 and self.zoom_range[1] == 1:
+            zx = zy = np.ones(n)
+        else:
+            zx = self.zoom_range[0] + (self.zoom_range[1] - self.zoom_range[0]) * u[:, 3]
+            zy = self.zoom_range[0] + (self.zoom_range[1] - self.zoom_range[0]) * u[:, 4]
+        c, s_ = np.cos(theta), np.sin(theta)
+        m00, m01, m10, m11 = c * zx, -s_ * zy, s_ * zx, c * zy
+        ox, oy = h / 2 + self.center, w / 2 + self.center
+        out = np.zeros(n, self.AFFINE_DTYPE)
+        out["m"][:, 0], out["m"][:, 1], out["m"][:, 2], out["m"][:, 3] = m00, m01, m10, m11
+        out["off"][:, 0] = ox + (c * tx - s_ * ty) - (m00 * ox + m01 * oy)
+        out["off"][:, 1] = oy + (s_ * tx + c * ty) - (m10 * ox + m11 * oy)
+        out["identity"] = (theta == 0) & (tx == 0) & (ty == 0) & (zx == 1) & (zy == 1)
+        out["flip_h"] = (u[:, 5] < 0.5) & self.horizontal_flip
+        out["flip_v"] = (u[:, 6] < 0.5) & self.vertical_flip
+        return out
+
     # ---- flow ---------------------------------------------------------------------------------
     def random_batch(self, trainer, batch, rng=np.random):
         """What one `next(datagen.flow(x, ...))` does to x: one independent draw per image.
@@ -144,6 +182,33 @@ class ImageDataGenerator:
         n, h, w = batch.shape[0], batch.shape[1], batch.shape[2]
         params: List[dict] = [self.get_random_transform((h, w), rng) for _ in range(n)]
         return trainer.augment(batch, self.pack(params, h, w)), params
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    """splitmix64's finaliser on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def counter_uniforms(seed: int, step: int, n: int) -> np.ndarray:
+    """u[b, j] in [0, 1), b < n, j < 7: the counter-based draws of cs_train_fit_step (csrc/train_api.hip: fit_u01) -- three
+    rounds of splitmix64's finaliser over (seed, step, 8 b + j), top 53 bits.  A step's draws depend on its key alone."""
+    key = _mix64(_mix64(np.array([seed], dtype=np.uint64)) ^ np.uint64(step))
+    ctr = (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(8) + np.arange(7, dtype=np.uint64)[None, :])
+    h = _mix64(key ^ ctr)
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def draw_transforms_c(gen: "ImageDataGenerator", seed: int, step: int, n: int, img_shape) -> np.ndarray:
+    """cs_train_draw_transforms itself (host-only entry of the library), as an AFFINE_DTYPE array."""
+    out = np.zeros(n, ImageDataGenerator.AFFINE_DTYPE)
+    cfg = gen.config()
+    L.check(L.load_library().cs_train_draw_transforms(C.byref(cfg), int(seed), int(step), n, int(img_shape[0]), int(img_shape[1]),
+                                                      out.ctypes.data))
+    return out
 
 
 class _GeneratorRng:

@@ -85,6 +85,7 @@ class Trainer:
         self.n_trainable, self.n_moving = nt.value, nm.value
         assert self.n_trainable == sum(int(np.prod(s)) for _, s in param_layout(self.channels))
         self._grad_tensor = None
+        self._fit_train = None            # the training set fit_step was last ordered after
 
     def close(self):
         if self._h:
@@ -123,6 +124,21 @@ class Trainer:
         assert kind == kind2 and n == n2
         L.check(self._lib.cs_train_step_async(self._h, xp, yp, n, kind, lr))
         L.order_torch_after(self._lib.cs_train_inputs_consumed, self._h, xb, yb)    # torch may reuse the batch's memory only after the copies
+
+    def fit_step(self, train, idx, aug_config=None, seed: int = 0, step: int = 0, lr: float = spec.ADAM_LR) -> None:
+        """cs_train_fit_step: ONE library call per fit() batch -- gathers train[idx] (a torch CUDA tensor [n, H, W] resident on this
+        trainer's device; idx: a C-contiguous int32 numpy array), draws and applies the batch's augmentation to the input
+        (aug_config: ImageDataGenerator.config(), or None), forward + backward + Adam, no host synchronisation.  The caller keeps
+        `train` alive and unchanged while steps are in flight; metrics as for step_async."""
+        if idx.dtype != np.int32 or not idx.flags["C_CONTIGUOUS"]:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if self._fit_train is not train:                      # ordered after whatever produced the training set, once
+            if not train.is_contiguous() or str(train.dtype) != "torch.float32":
+                raise ValueError("train must be a contiguous float32 CUDA tensor")
+            L.order_after_torch(self._lib.cs_train_wait_stream, self._h, train)
+            self._fit_train = train
+        L.check(self._lib.cs_train_fit_step(self._h, train.data_ptr(), train.shape[0], idx.ctypes.data, idx.shape[0],
+                                            C.byref(aug_config) if aug_config is not None else None, int(seed), int(step), lr))
 
     def read_metrics(self, reset: bool = True) -> Tuple[float, float, int]:
         """(mean loss, mean mae, steps) over the step_async calls since the last reset: one host round trip."""

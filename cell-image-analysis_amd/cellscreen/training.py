@@ -135,8 +135,13 @@ class ImprovedAnomalyDetectionTraining:
                     warnings.warn(f"sync_bn is available for the reference 64x64 graph only; training {tuple(X.shape[1:3])} / {tuple(ae0.channels)} "
                                   f"with per-rank BatchNormalization statistics (pass sync_bn=False to silence this)")
         augment = self.augment
+        # one GPU, the reference's generator (or none): a fit() batch is ONE library call -- gather, the batch's keyed augmentation
+        # draws, forward + backward + Adam (cs_train_fit_step); a caller-supplied hook and the data-parallel step keep the
+        # gather -> augment -> step sequence of separate calls
+        fit_cfg, use_fit = None, world == 1 and (augment == "reference" or augment is None) and hasattr(tr, "fit_step")
         if augment == "reference":                                                  # datagen of :246-254
-            from .augment import reference_augment
+            from .augment import ImageDataGenerator, reference_augment
+            fit_cfg = ImageDataGenerator.reference().config()
             augment = reference_augment(tr)
         rng = np.random.default_rng(self.seed)                                      # same stream on every rank
         aug_rng = np.random.default_rng(self.seed + 1 + rank)
@@ -148,9 +153,14 @@ class ImprovedAnomalyDetectionTraining:
         best_path = os.path.join(self.output_dir, "best_autoencoder.keras")
         try:
             for epoch in range(self.epochs):                                        # epochs=100 (:289)
-                order = torch.from_numpy(rng.permutation(len(X_train))).to(dev)     # flow(..., shuffle=True); one upload per epoch
+                perm = rng.permutation(len(X_train))                                # flow(..., shuffle=True)
                 tl = tm = 0.0
-                for s in range(steps):
+                if use_fit:
+                    idx = np.ascontiguousarray(perm[:steps * self.batch_size], dtype=np.int32).reshape(steps, self.batch_size)
+                    for s in range(steps):                                          # the augmentation key: (seed, global step)
+                        tr.fit_step(Xd, idx[s], fit_cfg, seed=self.seed + 1, step=epoch * steps + s, lr=lr)
+                order = torch.from_numpy(perm).to(dev) if not use_fit else None     # one upload per epoch
+                for s in range(steps if not use_fit else 0):
                     lo = s * self.batch_size + rank * local_b
                     yb = Xd[order[lo:lo + local_b]]                                 # gather on the device
                     xb = augment(yb, aug_rng) if augment is not None else yb        # input augmented, target not (:287)

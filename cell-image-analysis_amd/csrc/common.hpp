@@ -224,6 +224,9 @@ hipError_t launch_wgrad_generic(const float* xin, const float* dz, float* part, 
 hipError_t launch_recon_err(const float* recon, const float* x, int64_t n, int npix, float* errpart, hipStream_t stream);
 // training augmentation: affine bilinear resample (nearest fill) + flips, one image per workgroup
 hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s);
+// cs_train_fit_step: gather train[idx[b]] -> y_out[b] (unchanged) and x_out[b] (resampled by tf[b] when has_tf); tf / idx may be pinned host memory
+hipError_t launch_fit_gather(const float* train, const cs_aug_affine* tf, const int* idx, float* x_out, float* y_out, int64_t n, int H,
+                             int W, bool has_tf, hipStream_t s);
 // one launch for every operand pack of a training step: transposed = 0 forward fragments, 1 backward-data fragments,
 // 2 conv7's effective weights (cin/cout ignored)
 struct PackJob { const float* src; float* dst; int cin, cout, transposed, blocks; };

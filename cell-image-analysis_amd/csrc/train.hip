@@ -973,6 +973,49 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
     }
 }
 
+// cs_train_fit_step: block b gathers crop idx[b] of the resident training set, writes it unchanged as the target and resampled
+// (the arithmetic of augment_kernel) as the input.  tf / idx live in pinned host memory (32 x 60 bytes per step).
+__global__ __launch_bounds__(256) void fit_gather_kernel(const float* __restrict__ train, const cs_aug_affine* __restrict__ tf,
+                                                         const int* __restrict__ idx, float* __restrict__ x_out,
+                                                         float* __restrict__ y_out, int H, int W, int has_tf)
+{
+    const float* src = train + (size_t)idx[blockIdx.x] * H * W;
+    float* dx = x_out + (size_t)blockIdx.x * H * W;
+    float* dy = y_out + (size_t)blockIdx.x * H * W;
+    cs_aug_affine a;
+    a.identity = 1; a.flip_h = 0; a.flip_v = 0;
+    if (has_tf) a = tf[blockIdx.x];
+    for (int p = threadIdx.x; p < H * W; p += 256) {
+        const int r = p / W, c = p - r * W;
+        const float s0 = src[p];
+        dy[p] = s0;
+        float v;
+        if (a.identity) {
+            v = s0;
+        } else {
+            double rr = a.m[0] * (double)r + a.m[1] * (double)c + a.off[0];
+            double cc = a.m[2] * (double)r + a.m[3] * (double)c + a.off[1];
+            rr = fmin(fmax(rr, 0.0), (double)(H - 1));
+            cc = fmin(fmax(cc, 0.0), (double)(W - 1));
+            const int r0 = min((int)floor(rr), H - 2), c0 = min((int)floor(cc), W - 2);
+            const double fr = rr - (double)r0, fc = cc - (double)c0;
+            const double x00 = src[r0 * W + c0], x01 = src[r0 * W + c0 + 1];
+            const double x10 = src[(r0 + 1) * W + c0], x11 = src[(r0 + 1) * W + c0 + 1];
+            v = (float)((1.0 - fr) * ((1.0 - fc) * x00 + fc * x01) + fr * ((1.0 - fc) * x10 + fc * x11));
+        }
+        const int ro = a.flip_v ? H - 1 - r : r, co = a.flip_h ? W - 1 - c : c;
+        dx[ro * W + co] = v;
+    }
+}
+
+hipError_t launch_fit_gather(const float* train, const cs_aug_affine* tf, const int* idx, float* x_out, float* y_out, int64_t n, int H,
+                             int W, bool has_tf, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fit_gather_kernel, dim3((unsigned)n), dim3(256), 0, s, train, tf, idx, x_out, y_out, H, W, has_tf ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_augment(const float* in, const cs_aug_affine* tf_dev, float* out, int64_t n, int H, int W, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;

@@ -471,6 +471,115 @@ int cs_train_step_async(cs_trainer* t, const float* x, const float* y, int64_t b
     return repack(t);
 }
 
+// ---- cs_train_fit_step: the generator's draws on the host, counter-based -------------------------------------------------
+// u(seed, step, b, j) in [0, 1): three rounds of splitmix64's finaliser over the key, top 53 bits.  cellscreen/augment.py
+// (counter_uniforms) is the same function; tests/test_augment_cpu.py holds the two together.
+static inline uint64_t fit_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline double fit_u01(uint64_t seed, uint64_t step, uint64_t b, uint64_t j)
+{
+    const uint64_t h = fit_mix64(fit_mix64(fit_mix64(seed) ^ step) ^ (b * 8 + j));
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// One image's transform from its seven uniforms: Keras's get_random_transform (theta, tx = height shift, ty = width shift, zx, zy,
+// flip_h, flip_v) and apply_affine_transform's matrix (rotation . shift . zoom about the image centre) in the closed form of
+// cellscreen/augment.py: ImageDataGenerator.random_transforms.
+static void fit_transform(const cs_aug_config& c, const double u[7], int H, int W, cs_aug_affine* o)
+{
+    const double h = (double)H, w = (double)W;
+    const double theta_deg = c.rotation_range != 0.0 ? -c.rotation_range + (c.rotation_range - -c.rotation_range) * u[0] : 0.0;
+    const double theta = theta_deg * (3.14159265358979323846 / 180.0);
+    double tx = 0.0, ty = 0.0;
+    if (c.height_shift_range != 0.0) tx = (-c.height_shift_range + (c.height_shift_range - -c.height_shift_range) * u[1]) * (c.height_shift_range < 1.0 ? h : 1.0);
+    if (c.width_shift_range != 0.0) ty = (-c.width_shift_range + (c.width_shift_range - -c.width_shift_range) * u[2]) * (c.width_shift_range < 1.0 ? w : 1.0);
+    double zx = 1.0, zy = 1.0;
+    if (!(c.zoom_lo == 1.0 && c.zoom_hi == 1.0)) {
+        zx = c.zoom_lo + (c.zoom_hi - c.zoom_lo) * u[3];
+        zy = c.zoom_lo + (c.zoom_hi - c.zoom_lo) * u[4];
+    }
+    const double cs_ = std::cos(theta), sn = std::sin(theta);
+    const double m00 = cs_ * zx, m01 = -sn * zy, m10 = sn * zx, m11 = cs_ * zy;
+    const double ox = h / 2 + c.center, oy = w / 2 + c.center;
+    o->m[0] = m00; o->m[1] = m01; o->m[2] = m10; o->m[3] = m11;
+    o->off[0] = ox + (cs_ * tx - sn * ty) - (m00 * ox + m01 * oy);
+    o->off[1] = oy + (sn * tx + cs_ * ty) - (m10 * ox + m11 * oy);
+    o->identity = (theta == 0.0 && tx == 0.0 && ty == 0.0 && zx == 1.0 && zy == 1.0) ? 1 : 0;
+    o->flip_h = (u[5] < 0.5 && c.horizontal_flip) ? 1 : 0;
+    o->flip_v = (u[6] < 0.5 && c.vertical_flip) ? 1 : 0;
+    o->reserved = 0;
+}
+
+int cs_train_draw_transforms(const cs_aug_config* aug, uint64_t seed, uint64_t step, int64_t n, int32_t height, int32_t width,
+                             cs_aug_affine* out)
+{
+    if (!aug || !out || n < 0 || height <= 0 || width <= 0) return fail(CS_ERR_INVALID, "cs_train_draw_transforms: NULL argument or bad size");
+    if (!(aug->zoom_lo > 0.0) || aug->zoom_hi < aug->zoom_lo) return fail(CS_ERR_INVALID, "cs_aug_config: zoom range [%g, %g]", aug->zoom_lo, aug->zoom_hi);
+    for (int64_t b = 0; b < n; ++b) {
+        double u[7];
+        for (int j = 0; j < 7; ++j) u[j] = fit_u01(seed, step, (uint64_t)b, (uint64_t)j);
+        fit_transform(*aug, u, height, width, out + b);
+    }
+    return CS_OK;
+}
+
+int cs_train_fit_step(cs_trainer* t, const float* train_device, int64_t n_train, const int32_t* idx, int64_t batch,
+                      const cs_aug_config* aug, uint64_t seed, uint64_t step, float lr)
+{
+    if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
+    if (!train_device || !idx || batch <= 0 || n_train <= 0) return fail(CS_ERR_INVALID, "train/idx NULL or batch, n_train <= 0");
+    for (int64_t b = 0; b < batch; ++b)
+        if (idx[b] < 0 || idx[b] >= n_train) return fail(CS_ERR_INVALID, "idx[%lld] = %d is outside the training set of %lld crops", (long long)b, idx[b], (long long)n_train);
+    HIPCHK(hipSetDevice(t->device));
+    int rc = t->ref ? ensure_batch(t, batch) : gen_train_ensure_batch(t, batch);
+    if (rc) return rc;
+    // {transforms, indices} of this step in a pinned slot the gather kernel reads directly; a slot is reused once its kernel ran
+    const size_t need = (size_t)batch * (sizeof(cs_aug_affine) + sizeof(int32_t));
+    if (need > t->fit_pin_slot) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        if (t->fit_pin) { (void)hipHostFree(t->fit_pin); t->fit_pin = nullptr; }
+        HIPCHK(hipHostMalloc(&t->fit_pin, need * cs_trainer::FIT_SLOTS, hipHostMallocDefault));
+        t->fit_pin_slot = need;
+        for (int k = 0; k < cs_trainer::FIT_SLOTS; ++k) {
+            t->fit_used[k] = false;
+            if (!t->ev_fit[k]) HIPCHK(hipEventCreateWithFlags(&t->ev_fit[k], hipEventDisableTiming));
+        }
+    }
+    const int slot = t->fit_next;
+    t->fit_next = (slot + 1) % cs_trainer::FIT_SLOTS;
+    if (t->fit_used[slot]) HIPCHK(hipEventSynchronize(t->ev_fit[slot]));
+    char* pin = (char*)t->fit_pin + (size_t)slot * t->fit_pin_slot;
+    cs_aug_affine* tf = (cs_aug_affine*)pin;
+    int32_t* ix = (int32_t*)(pin + (size_t)batch * sizeof(cs_aug_affine));
+    if (aug && (rc = cs_train_draw_transforms(aug, seed, step, batch, t->H, t->W, tf))) return rc;
+    memcpy(ix, idx, (size_t)batch * sizeof(int32_t));
+    if (!t->ref) {
+        // run-time-shaped architectures: their step synchronises by itself (cs_train_step_async's rule)
+        const size_t bytes = (size_t)batch * t->H * t->W * sizeof(float);
+        if ((rc = t->aug_in.ensure(bytes)) || (rc = t->aug_out.ensure(bytes))) return rc;
+        LCHK(launch_fit_gather(train_device, tf, ix, t->aug_out.as<float>(), t->aug_in.as<float>(), batch, t->H, t->W, aug != nullptr, t->stream));
+        HIPCHK(hipEventRecord(t->ev_fit[slot], t->stream));
+        t->fit_used[slot] = true;
+        return cs_train_step_async(t, t->aug_out.as<float>(), t->aug_in.as<float>(), batch, CS_MEM_DEVICE, lr);
+    }
+    LCHK(launch_fit_gather(train_device, tf, ix, t->x.as<float>(), t->y.as<float>(), batch, t->H, t->W, aug != nullptr, t->stream));
+    HIPCHK(hipEventRecord(t->ev_fit[slot], t->stream));
+    t->fit_used[slot] = true;
+    HIPCHK(hipEventRecord(t->ev_in, t->stream));          // cs_train_inputs_consumed: the training set has been read
+    if ((rc = fb_enqueue(t, batch))) return rc;
+    t->step += 1;
+    const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
+    const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+    LCHK(launch_adam(t->P.as<float>(), t->G, t->M.as<float>(), t->V.as<float>(), t->nparam, nullptr, t->cfg.beta1, t->cfg.beta2,
+                     t->cfg.adam_eps, t->stream, alpha, t->scal.as<float>(), t->macc.as<double>()));
+    return repack(t);
+}
+
 int cs_train_inputs_consumed(cs_trainer* t, void* hip_stream)
 {
     if (!t) return fail(CS_ERR_INVALID, "trainer handle is NULL");

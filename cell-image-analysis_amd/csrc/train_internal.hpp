@@ -58,10 +58,19 @@ struct cs_trainer {
     hipEvent_t ev_aug[AUG_SLOTS] = {nullptr};
     bool aug_used[AUG_SLOTS] = {false};
     int aug_next = 0;
+    // cs_train_fit_step: per-step {transforms, indices} in a pinned ring the gather kernel reads directly
+    static constexpr int FIT_SLOTS = 16;
+    void* fit_pin = nullptr;
+    size_t fit_pin_slot = 0;
+    hipEvent_t ev_fit[FIT_SLOTS] = {nullptr};
+    bool fit_used[FIT_SLOTS] = {false};
+    int fit_next = 0;
     ~cs_trainer()
     {
         if (hloss) (void)hipHostFree(hloss);
         if (aug_pin) (void)hipHostFree(aug_pin);
+        if (fit_pin) (void)hipHostFree(fit_pin);
+        for (auto& e : ev_fit) if (e) (void)hipEventDestroy(e);
         if (ev_in) (void)hipEventDestroy(ev_in);
         for (auto& e : ev_aug) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_dz) if (e) (void)hipEventDestroy(e);

@@ -408,6 +408,29 @@ typedef struct cs_aug_affine {
  * reader orders itself with cs_train_inputs_consumed or a synchronising call.  CS_MEM_HOST returns when out is written. */
 int cs_train_augment(cs_trainer *t, const float *x, int64_t n, const cs_aug_affine *tf, float *out, int kind);
 
+/* The generator's settings (Keras names; CAE_improved_modeltrain.py:246-254 is {2, 0.02, 0.02, 0.98, 1.02, 1, 1, -0.5}).
+ * Shift ranges below 1 are fractions of the image side, as in Keras; center: the transform's centre is size/2 + center. */
+typedef struct cs_aug_config {
+    double rotation_range;                        /* degrees: theta ~ U(-r, r) */
+    double width_shift_range, height_shift_range;
+    double zoom_lo, zoom_hi;                      /* zx, zy ~ U(lo, hi) each */
+    int32_t horizontal_flip, vertical_flip;
+    double center;
+} cs_aug_config;
+/* The n transforms of fit() step `step`: image b's seven draws (theta, tx = height shift, ty = width shift, zx, zy, flip_h,
+ * flip_v -- Keras's get_random_transform order) are u(seed, step, b, j), j = 0..6, of a counter-based generator (three rounds
+ * of splitmix64 over the key; cellscreen/augment.py has the same function), so a step's augmentation does not depend on how many
+ * were drawn before it or on which rank draws it.  Host only, no device needed. */
+int cs_train_draw_transforms(const cs_aug_config *aug, uint64_t seed, uint64_t step, int64_t n, int32_t height, int32_t width,
+                             cs_aug_affine *out);
+/* One fit() batch straight from a training set resident on the handle's device (CAE_improved_modeltrain.py:286-293:
+ * datagen.flow(X_train, X_train, batch_size=32) -> one step of model.fit): gathers train[idx[b]], b < batch, draws the
+ * batch's transforms (cs_train_draw_transforms; aug == NULL: none), resamples the INPUT only -- the target stays the original
+ * crop -- and enqueues forward + backward + Adam like cs_train_step_async: no host synchronisation, no other call, no
+ * intermediate tensor of the caller's.  idx: host array (copied before the call returns).  Metrics: cs_train_read_metrics. */
+int cs_train_fit_step(cs_trainer *t, const float *train_device, int64_t n_train, const int32_t *idx, int64_t batch,
+                      const cs_aug_config *aug, uint64_t seed, uint64_t step, float lr);
+
 /* Copies to host (each pointer may be NULL): trainable parameters, moving statistics, last gradients. */
 int cs_train_export(cs_trainer *t, float *params_host, float *moving_host, float *grads_host);
 /* Stage tap for parity tests: copies one tensor of the last forward_backward to host.

@@ -105,3 +105,47 @@ def test_vectorised_batch_draw_is_the_scalar_algebra():
     # no rotation / shift / zoom configured: every draw is the identity (+ flips)
     flips = ImageDataGenerator(horizontal_flip=True).random_transforms(50, (64, 64), np.random.default_rng(1))
     assert flips["identity"].all() and 5 < flips["flip_h"].sum() < 45 and not flips["flip_v"].any()
+
+
+def test_keyed_transforms_of_fit_step_match_the_library_and_keras_draw():
+    """cs_train_fit_step draws a batch's transforms itself from a counter-based generator keyed (seed, step, image): the C function
+    (cs_train_draw_transforms, host only) against its Python mirror -- the same seven uniforms per image in Keras's
+    get_random_transform order (theta, tx = height shift, ty = width shift, zx, zy, flip_h, flip_v), reduced with the closed form of
+    random_transforms -- and that closed form against the per-image Keras matrix algebra (affine())."""
+    from cellscreen import augment as A
+    gens = [A.ImageDataGenerator.reference(),
+            A.ImageDataGenerator(rotation_range=25, width_shift_range=0.3, height_shift_range=3.0, zoom_range=(0.7, 1.4), horizontal_flip=True),
+            A.ImageDataGenerator(zoom_range=0.0, vertical_flip=True),                      # nothing but a flip: identity resampling
+            A.ImageDataGenerator(rotation_range=10, center=0.5)]
+    for gi, g in enumerate(gens):
+        for seed, step, shape in ((42, 0, (64, 64)), (43, 1249, (64, 64)), (2 ** 40 + 7, 10 ** 9, (128, 96))):
+            py = g.keyed_transforms(seed, step, 32, shape)
+            c = A.draw_transforms_c(g, seed, step, 32, shape)
+            for k in ("m", "off"):
+                assert np.allclose(py[k], c[k], rtol=0, atol=1e-12), (gi, k)                # the same doubles up to an fma contraction
+            for k in ("identity", "flip_h", "flip_v"):
+                assert np.array_equal(py[k], c[k]), (gi, k)
+            # ... and the closed form is Keras's matrix product for the same parameters
+            u = A.counter_uniforms(seed, step, 32)
+            for b in (0, 5, 31):
+                r = g.rotation_range
+                p = dict(theta=(-r + 2 * r * u[b, 0]) if r else 0.0,
+                         tx=(-g.height_shift_range + 2 * g.height_shift_range * u[b, 1]) * (shape[0] if g.height_shift_range < 1 else 1.0) if g.height_shift_range else 0.0,
+                         ty=(-g.width_shift_range + 2 * g.width_shift_range * u[b, 2]) * (shape[1] if g.width_shift_range < 1 else 1.0) if g.width_shift_range else 0.0,
+                         zx=g.zoom_range[0] + (g.zoom_range[1] - g.zoom_range[0]) * u[b, 3] if g.zoom_range != (1.0, 1.0) else 1.0,
+                         zy=g.zoom_range[0] + (g.zoom_range[1] - g.zoom_range[0]) * u[b, 4] if g.zoom_range != (1.0, 1.0) else 1.0,
+                         flip_h=bool(u[b, 5] < 0.5) and g.horizontal_flip, flip_v=bool(u[b, 6] < 0.5) and g.vertical_flip)
+                am = g.affine(p, shape[0], shape[1])
+                if am is None:
+                    assert c["identity"][b] == 1
+                else:
+                    assert np.allclose(np.ravel(am[0]), c["m"][b], rtol=0, atol=1e-12) and np.allclose(am[1], c["off"][b], rtol=0, atol=1e-10)
+                assert bool(c["flip_h"][b]) == p["flip_h"] and bool(c["flip_v"][b]) == p["flip_v"]
+    # the generator: uniform, and a step's draws depend on its key alone
+    u = np.concatenate([A.counter_uniforms(7, s, 64) for s in range(200)])
+    assert u.shape == (12800, 7) and 0.0 <= u.min() and u.max() < 1.0
+    assert np.abs(u.mean(axis=0) - 0.5).max() < 0.02 and np.abs(u.var(axis=0) - 1.0 / 12).max() < 0.01
+    assert np.abs(np.corrcoef(u.T) - np.eye(7)).max() < 0.05
+    assert np.array_equal(A.counter_uniforms(7, 3, 64)[:32], A.counter_uniforms(7, 3, 32))
+    assert not np.array_equal(A.counter_uniforms(7, 3, 32), A.counter_uniforms(7, 4, 32))
+    assert not np.array_equal(A.counter_uniforms(7, 3, 32), A.counter_uniforms(8, 3, 32))

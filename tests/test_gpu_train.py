@@ -163,6 +163,43 @@ def test_asynchronous_steps_are_the_synchronous_steps():
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("shape", ["reference", "generic"])
+def test_fit_step_is_gather_augment_and_step_in_one_call(shape):
+    """cs_train_fit_step: one library call per fit() batch -- gather train[idx] from the resident training set, the batch's keyed
+    augmentation draws (host, counter-based), resample the input only, forward + backward + Adam.  Against the same batch taken
+    apart: torch gather -> Trainer.augment with ImageDataGenerator.keyed_transforms -> step_async, on a twin trainer: the same
+    weights and moving statistics bit for bit, the same epoch metrics; without augmentation: input == target."""
+    import torch
+    from cellscreen.augment import ImageDataGenerator
+    from cellscreen._lib import CellScreenError
+    hw, ch = ((64, 64), spec.CHANNELS) if shape == "reference" else ((64, 128), (8, 16, 32, 32, 16, 8, 1))
+    w = synth.random_cae(seed=12, hw=hw, channels=ch, trivial_bn=True)
+    a, b = Trainer(w), Trainer(w)
+    gen = ImageDataGenerator.reference()
+    X = torch.from_numpy(synth.blob_crops(4, 200, hw=hw)).cuda()
+    rng = np.random.default_rng(5)
+    try:
+        for step in range(5):
+            idx = rng.permutation(200)[:32].astype(np.int32)
+            cfg = gen.config() if step != 3 else None                                   # one step without augmentation
+            a.fit_step(X, idx, cfg, seed=77, step=step, lr=1e-3)
+            yb = X[torch.from_numpy(idx.astype(np.int64)).cuda()].contiguous()
+            xb = b.augment(yb, gen.keyed_transforms(77, step, 32, hw)) if cfg is not None else yb
+            b.step_async(xb, yb, 1e-3)
+        la, ma, na = a.read_metrics()
+        lb, mb, nb = b.read_metrics()
+        assert na == nb == 5 and la == lb and ma == mb
+        pa, mva = a.export_flat()
+        pb, mvb = b.export_flat()
+        assert np.array_equal(pa, pb) and np.array_equal(mva, mvb)
+        with pytest.raises(CellScreenError):
+            a.fit_step(X, np.array([0, 200], np.int32), None)                           # outside the training set: refused, nothing enqueued
+        with pytest.raises(CellScreenError):
+            a.fit_step(X, np.array([-1], np.int32), None)
+    finally:
+        a.close(); b.close()
+
+
 def test_training_trajectory_tracks_the_oracle():
     """Several full steps.  Adam's early updates are ~lr*sign(g), so fp32 and fp64 trajectories
     separate at the 1e-3 level within a few steps (the numpy oracle in float32 does the same
