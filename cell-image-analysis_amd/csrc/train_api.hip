@@ -447,9 +447,21 @@ int cs_train_step_async(cs_trainer* t, const float* x, const float* y, int64_t b
     if (!t) return fail(CS_ERR_INVALID, "trainer is NULL");
     if (!x || !y || batch <= 0) return fail(CS_ERR_INVALID, "x/y NULL or batch <= 0");
     if (kind != CS_MEM_HOST && kind != CS_MEM_DEVICE) return fail(CS_ERR_INVALID, "bad mem kind");
-    if (!t->ref || kind == CS_MEM_HOST) {
-        // run-time-shaped architectures (their step synchronises by itself) and pageable host batches: a synchronous step,
-        // its scalars added on the host
+    if (!t->ref && kind == CS_MEM_DEVICE) {
+        // run-time-shaped architectures: the same asynchronous step on train_generic.hip's kernels
+        HIPCHK(hipSetDevice(t->device));
+        int rc = gen_train_fb_enqueue(t, x, y, batch, kind);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(t->ev_in, t->stream));
+        t->step += 1;
+        const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
+        const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+        LCHK(launch_adam(t->P.as<float>(), t->G, t->M.as<float>(), t->V.as<float>(), t->nparam, nullptr, t->cfg.beta1, t->cfg.beta2,
+                         t->cfg.adam_eps, t->stream, alpha, t->scal.as<float>(), t->macc.as<double>()));
+        return gen_train_repack(t);
+    }
+    if (kind == CS_MEM_HOST) {
+        // pageable host batches: a synchronous step, its scalars added on the host
         float l = 0.0f, m = 0.0f;
         int rc = cs_train_step(t, x, y, batch, kind, lr, &l, &m);
         if (rc) return rc;

@@ -99,25 +99,27 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
         const long cell = row / H;
         const int y = (int)(row - cell * H);
         __syncthreads();                                    // the previous row's MFMAs are done with the staged rows
-        // activation rows y - 1 .. y + 1 at conv-grid columns -1 .. W
+        // activation rows y - 1 .. y + 1 at conv-grid columns -1 .. W live in a three-slot ring (row yy in slot (yy + 3) % 3):
+        // inside a cell a conv row brings ONE new row (y + 1); the part's first row and a cell's first row stage all three
+        const int d0 = (row == r0 || y == 0) ? 0 : 2, nd = 3 - d0;
         if ((cin & 3) == 0) {
             const int c4n = cin >> 2, per_row = (W + 2) * c4n;
-            for (int e = tid; e < 3 * per_row; e += 256) {
-                const int d = e / per_row, rem = e - d * per_row, xx = rem / c4n - 1, c4 = rem - (xx + 1) * c4n;
+            for (int e = tid; e < nd * per_row; e += 256) {
+                const int dd = e / per_row, d = d0 + dd, rem = e - dd * per_row, xx = rem / c4n - 1, c4 = rem - (xx + 1) * c4n;
                 const int yy = y + d - 1;
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (yy >= 0 && yy < H && xx >= 0 && xx < W)
                     v = *(const f32x4*)(g.xin + ((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws + (g.ups ? xx >> 1 : xx)) * cin + 4 * c4);
-                *(f32x4*)(Xs + (d * (W + 2) + xx + 1) * xs_ + 4 * c4) = v;
+                *(f32x4*)(Xs + (((yy + 3) % 3) * (W + 2) + xx + 1) * xs_ + 4 * c4) = v;
             }
         } else {
             const int per_row = (W + 2) * cin;
-            for (int e = tid; e < 3 * per_row; e += 256) {
-                const int d = e / per_row, rem = e - d * per_row, xx = rem / cin - 1, c = rem - (xx + 1) * cin;
+            for (int e = tid; e < nd * per_row; e += 256) {
+                const int dd = e / per_row, d = d0 + dd, rem = e - dd * per_row, xx = rem / cin - 1, c = rem - (xx + 1) * cin;
                 const int yy = y + d - 1;
                 float v = 0.0f;
                 if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = g.xin[((cell * Hs + (g.ups ? yy >> 1 : yy)) * Ws + (g.ups ? xx >> 1 : xx)) * cin + c];
-                Xs[(d * (W + 2) + xx + 1) * xs_ + c] = v;
+                Xs[(((yy + 3) % 3) * (W + 2) + xx + 1) * xs_ + c] = v;
             }
         }
         const float* dzr = g.dz + ((cell * H + y) * W) * cout;
@@ -137,13 +139,14 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgArgs g)
         if (active) {
             const float* xa = Xs + kq * xs_ + (ciok ? ci : 0);       // tap (d, dx) of pixel x: row d, staged column x + dx
             const float* zb = Zs + kq * zs_;
+            const int rslot[3] = {(y + 2) % 3, y % 3, (y + 1) % 3};       // ring slots of rows y - 1, y, y + 1
             for (int x0 = 0; x0 < W; x0 += 4) {
                 float b[NCO], a[9];
 #pragma unroll
                 for (int j = 0; j < NCO; ++j) b[j] = cok[j] ? zb[x0 * zs_ + co[j]] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const float v = xa[((t / 3) * (W + 2) + x0 + t % 3) * xs_];
+                    const float v = xa[(rslot[t / 3] * (W + 2) + x0 + t % 3) * xs_];
                     a[t] = ciok ? v : 0.0f;
                 }
 #pragma unroll
@@ -329,7 +332,11 @@ static int gen_copy_in(cs_trainer* t, DevBuf& dst, const float* src, int kind, s
     return CS_OK;
 }
 
-int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae)
+// Forward + backward of one batch as stream work only (no host synchronisation once the reduction descriptors of this batch
+// size are uploaded).  The weight gradient of a layer needs only that layer's dz and input: it runs on a second stream beside the
+// backward-data conv and the BatchNormalization-backward kernels of the layers below (a third of the step's kernel time at
+// batch 32 of the 128 x 128 variant: profiles/r04_*_train_variant_trace.txt); both streams join before the partial sums are reduced.
+int gen_train_fb_enqueue(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind)
 {
     int rc = gen_train_ensure_batch(t, batch);
     if (rc) return rc;
@@ -365,6 +372,12 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
     // ---- backward
     LCHK(launch_loss_dz(t->out.as<float>(), t->y.as<float>(), (long)B * npix, t->dz[last].as<float>(), t->dzsum_part[last].as<float>(),
                         &t->np_b[last], s, t->errpart.as<float>(), B * 4, t->scal.as<float>()));
+    if (!t->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+        for (int l = 0; l < TR_MAXL; ++l) HIPCHK(hipEventCreateWithFlags(&t->ev_dz[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&t->ev_wg, hipEventDisableTiming));
+    }
+    hipStream_t s2 = t->stream2;
     for (int l = last; l >= 0; --l) {
         const int C = t->ch[l], pool = l < t->n_enc, ups = l > t->n_enc;
         if (l < last) {
@@ -378,8 +391,10 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
                                   &t->np_b[l], s));
         }
         const float* in = l == 0 ? t->x.as<float>() : t->a[l - 1].as<float>();
+        HIPCHK(hipEventRecord(t->ev_dz[l], s));
+        HIPCHK(hipStreamWaitEvent(s2, t->ev_dz[l], 0));
         LCHK(launch_wgrad_generic(in, t->dz[l].as<float>(), t->wpart[l].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), C, ups, TRAIN_MAX_PARTS,
-                                  &t->np_w[l], s));
+                                  &t->np_w[l], s2));
         if (l > 0) {   // dL/d(input of conv l): conv of dz with the flipped kernel, channel roles swapped
             float* dst = ups ? t->dup.as<float>() : t->da[l - 1].as<float>();
             if (t->x3t[l])
@@ -391,21 +406,32 @@ int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, in
             if (ups) LCHK(launch_sumpool2x2(t->dup.as<float>(), t->da[l - 1].as<float>(), B, t->gh[l], t->gw[l], t->cin(l), s));
         }
     }
+    HIPCHK(hipEventRecord(t->ev_wg, s2));
+    HIPCHK(hipStreamWaitEvent(s, t->ev_wg, 0));
     // ---- all partial sums -> flat gradient, in workgroup order
-    std::vector<ReduceDesc> d(2 * t->n_conv);
     long total = 0;
-    for (int l = 0; l < t->n_conv; ++l) {
-        const long klen = 9L * t->cin(l) * t->ch[l];
-        d[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
-        d[2 * l + 1] = ReduceDesc{t->off_b[l], (long)t->ch[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)t->ch[l]};
-        total += klen + t->ch[l];
+    for (int l = 0; l < t->n_conv; ++l) total += 9L * t->cin(l) * t->ch[l] + t->ch[l];
+    if (t->descs_batch != B) {          // the partial counts depend on the batch size only; hdescs outlives the copy
+        for (int l = 0; l < t->n_conv; ++l) {
+            const long klen = 9L * t->cin(l) * t->ch[l];
+            t->hdescs[2 * l] = ReduceDesc{t->off_k[l], klen, t->wpart[l].as<float>(), t->np_w[l], klen};
+            t->hdescs[2 * l + 1] = ReduceDesc{t->off_b[l], (long)t->ch[l], t->dzsum_part[l].as<float>(), t->np_b[l], (long)t->ch[l]};
+        }
+        HIPCHK(hipMemcpyAsync(t->descs.p, t->hdescs, 2 * t->n_conv * sizeof(ReduceDesc), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        t->descs_batch = B;
     }
-    HIPCHK(hipMemcpyAsync(t->descs.p, d.data(), d.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // `d` is a local: the copy must finish before it dies
     LCHK(launch_reduce_all(t->descs.as<ReduceDesc>(), 2 * t->n_conv, total, G, s));
+    return CS_OK;
+}
+
+int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae)
+{
+    int rc = gen_train_fb_enqueue(t, x, y, batch, kind);
+    if (rc) return rc;
     float h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h, t->scal.p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpyAsync(h, t->scal.p, 8, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
     if (loss) *loss = h[0];
     if (mae) *mae = h[1];
     return CS_OK;

@@ -90,5 +90,6 @@ struct cs_trainer {
 int gen_train_setup(cs_trainer* t);                      // buffers that depend on the architecture only
 int gen_train_repack(cs_trainer* t);                     // flipped / transposed kernels for the backward-data convs
 int gen_train_ensure_batch(cs_trainer* t, int64_t b);
+int gen_train_fb_enqueue(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind);
 int gen_train_forward_backward(cs_trainer* t, const float* x, const float* y, int64_t batch, int kind, float* loss, float* mae);
 int gen_train_eval(cs_trainer* t, const float* x, const float* y, int64_t n, int kind, float* loss, float* mae);

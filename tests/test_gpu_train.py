@@ -174,7 +174,7 @@ def test_fit_step_is_gather_augment_and_step_in_one_call(shape):
     from cellscreen._lib import CellScreenError
     hw, ch = ((64, 64), spec.CHANNELS) if shape == "reference" else ((64, 128), (8, 16, 32, 32, 16, 8, 1))
     w = synth.random_cae(seed=12, hw=hw, channels=ch, trivial_bn=True)
-    a, b = Trainer(w), Trainer(w)
+    a, b, c = Trainer(w), Trainer(w), Trainer(w)
     gen = ImageDataGenerator.reference()
     X = torch.from_numpy(synth.blob_crops(4, 200, hw=hw)).cuda()
     rng = np.random.default_rng(5)
@@ -186,18 +186,21 @@ def test_fit_step_is_gather_augment_and_step_in_one_call(shape):
             yb = X[torch.from_numpy(idx.astype(np.int64)).cuda()].contiguous()
             xb = b.augment(yb, gen.keyed_transforms(77, step, 32, hw)) if cfg is not None else yb
             b.step_async(xb, yb, 1e-3)
+            c.step(xb, yb, 1e-3)                                                        # ... and the synchronous step (one stream sync per step)
         la, ma, na = a.read_metrics()
         lb, mb, nb = b.read_metrics()
         assert na == nb == 5 and la == lb and ma == mb
         pa, mva = a.export_flat()
         pb, mvb = b.export_flat()
+        pc, mvc = c.export_flat()
         assert np.array_equal(pa, pb) and np.array_equal(mva, mvb)
+        assert np.array_equal(pa, pc) and np.array_equal(mva, mvc)
         with pytest.raises(CellScreenError):
             a.fit_step(X, np.array([0, 200], np.int32), None)                           # outside the training set: refused, nothing enqueued
         with pytest.raises(CellScreenError):
             a.fit_step(X, np.array([-1], np.int32), None)
     finally:
-        a.close(); b.close()
+        a.close(); b.close(); c.close()
 
 
 def test_training_trajectory_tracks_the_oracle():
