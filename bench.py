@@ -513,7 +513,7 @@ def large_variant_leg(local_rank, seed, n=8192, train_steps=200):
                 forward=fwd, train=train)
 
 
-def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
+def e2e_raw_leg(weights, n, seed, local_rank, chunk=65536):
     """improved_detection.py:98-99 -> :199 as one pipeline: raw uint16 bounding-box crops (ragged, sides U[32,100]) in PINNED host
     memory -> H2D (copy stream, chunk i + 1 under the kernels of chunk i) -> cs_preprocess (device -> device) -> cs_screen
     -> 18 B/cell back on the host."""
@@ -537,6 +537,20 @@ def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
         if m > 0:
             hv[lo:lo + m] = bpix[:m]
     proc = pp.Preprocessor(local_rank)
+    # this leg's detector is fit on what it screens: encoder features of PREPROCESSED raw crops (2,048 of another seed, the device
+    # fit of csrc/fit.hip), so its anomaly rates mean something -- about nu = 0.05 / 0.10 for crops from the training distribution
+    from cellscreen.detector_fit import fit_detector_device
+    from cellscreen.engine import Engine
+    tpix, toff, ths, tws = pp.pack_crops(synth.raw_crops(seed + 17, 2048, np.uint16, 32, 100))
+    tcrops = torch.empty((len(ths), 64, 64), dtype=torch.float32, device=dev)
+    proc.run_packed(torch.from_numpy(tpix.view(np.int16)).to(dev), toff, ths, tws, out=tcrops)
+    enc = Engine.from_weights(weights, device_id=local_rank)
+    tfeat = enc.encode(tcrops, which=0).cpu().numpy()
+    enc.close()
+    det_raw, _ = fit_detector_device(tfeat, device_id=local_rank)
+    eng = Engine.from_weights(weights, None, det_raw, device_id=local_rank)
+    eng.set_chunk(chunk)
+    del tcrops
     copy_stream = torch.cuda.Stream(device=dev)
     bounds = [(i, min(i + chunk, n)) for i in range(0, n, chunk)]
     span = max(int(off[b - 1] + sizes[b - 1] - off[a]) for a, b in bounds)
@@ -580,11 +594,15 @@ def e2e_raw_leg(eng, n, seed, local_rank, chunk=65536):
         dt = time.perf_counter() - t0
     finally:
         proc.close()
+        eng.close()
     return dict(value=round(n / dt, 1), unit="cells/s", wall_s=round(dt, 4), crops=n, chunk_crops=chunk,
                 h2d_bytes_per_cell=round(2.0 * total / n, 1), d2h_bytes_per_cell=18,
                 h2d_gbs=round(2.0 * total / dt / 1e9, 2), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
                 workload="%d raw uint16 crops, sides U[32,100] (4,096 distinct, repeated), pinned host -> cs_preprocess -> cs_screen -> host" % n,
-                anomaly_rate_conservative=round(float((res["cons_pred"] == -1).float().mean()), 4))
+                detector="fit on the encoder features of 2,048 preprocessed raw crops of another seed (device fit: nu = 0.05 / 0.10)",
+                n_sv=[int(det_raw.conservative.n_sv), int(det_raw.moderate.n_sv)],
+                anomaly_rate_conservative=round(float((res["cons_pred"] == -1).float().mean()), 4),
+                anomaly_rate_moderate=round(float((res["mod_pred"] == -1).float().mean()), 4))
 
 
 def small_n_leg(eng, seed):
@@ -861,7 +879,7 @@ def main():
             del x
             torch.cuda.empty_cache()
             try:
-                line["e2e_raw"] = e2e_raw_leg(eng, args.raw_crops, args.seed, local_rank)
+                line["e2e_raw"] = e2e_raw_leg(weights, args.raw_crops, args.seed, local_rank)
             except Exception as e:  # noqa: BLE001
                 line["e2e_raw"] = {"error": repr(e)}
             torch.cuda.empty_cache()

@@ -380,7 +380,7 @@ static int pack_svm(cs_model::Svm& s, const cs_ocsvm_params& p, int D, const cha
     if (p.n_sv <= 0 || !p.support_vectors || !p.dual_coef)
         return fail(CS_ERR_INVALID, "%s detector: n_sv=%d or NULL arrays", what, p.n_sv);
     s.nsv = p.n_sv;
-    s.nsv_pad = (p.n_sv + 255) / 256 * 256;
+    s.nsv_pad = (p.n_sv + 15) / 16 * 16;      // blocks of 16 support vectors (padding rows carry a zero coefficient: exact zeros, but they cost time)
     s.gamma = p.gamma;
     s.rho = p.rho;
     std::vector<double> svT((size_t)D * s.nsv_pad, 0.0), coef(s.nsv_pad, 0.0), svn(s.nsv_pad, 0.0);

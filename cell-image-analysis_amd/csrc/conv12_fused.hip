@@ -3,30 +3,34 @@
 //   conv2: Conv2D 32->64 on 32x32 + ReLU + BN + MaxPool  (:195-197)
 //
 // conv2 is Winograd F(4x4, 3x3) (interpolation points 0, +-1, +-2, inf): a 4x4 output tile costs 36
-// multiplies per channel pair where F(2x2,3x3) needed 64 -- 4,608 16x16x4 MFMAs per cell instead of
-// 8,192 (direct: 18,432).  Measured in fp32 emulation before adopting (tests/study_wino_error.py): p2 error
-// 1.6e-6 of its range, features 4.3e-7 of theirs (bar 1e-5).  conv1 (2.4 % of the path's MACs) is
-// computed inside the staging of conv2's input rows, so the 131 KB/cell p1 tensor (written by one kernel,
-// read by the next) and one launch disappear.
+// multiplies per channel pair where F(2x2,3x3) needed 64.  Measured in fp32 emulation before adopting
+// (tests/study_wino_error.py, tests/study_split_fp16.py): p2 error 1.1e-6 .. 1.6e-6 of its range, features 4.3e-7 of theirs
+// (bar 1e-5).  conv1 (2.4 % of the path's MACs) is computed inside the staging of conv2's input rows, so the 131 KB/cell p1
+// tensor (written by one kernel, read by the next) and one launch disappear.
 //
-// One 512-thread workgroup per CU (8 waves = 2 per SIMD, 152 KB of LDS) walks whole cells; a cell is four
-// GROUPS of 16 tiles (two tile rows = 8 conv2 rows).  Per group, four phases, one barrier after each:
-//   P1 conv1   wave (x-tile, 16-channel slice) computes the 8 new p1 rows of the group from the crop in
-//              LDS: three MFMAs per 16 pixels -- bf16 ones on the crop's split-bf16 records (template flag C1X3,
-//              the default; see the kernel's comment) or 16x16x4 fp32 ones with K = 9 padded to 12 -- vertical
-//              tile pair = the pool window; bias -> ReLU -> BN -> max; rows go to a 10-slot ring in LDS (slot =
-//              row mod 10; two rows carry over to the next group).
-//   P2 V=B^TdB thread (tile, channel) transforms its 6x6 patch (scalar LDS reads, conflict-free: a half
-//              wave reads 32 consecutive channels) and writes V in the A-operand order of the MFMAs.
+// Two forms (template flag H = cs_model_options.precision): H (CS_PRECISION_SPLIT16) -- both contractions as two-term fp16 splits on
+// v_mfma_f32_16x16x32_f16 with exact power-of-two operand scales from the crop's own maximum -- and !H (CS_PRECISION_FP32_EXACT) --
+// everything on v_mfma_f32_16x16x4_f32.
+//
+// One 512-thread workgroup per CU (8 waves = 2 per SIMD, 159 KB of LDS) walks whole cells; a cell is four
+// GROUPS of 16 tiles (two tile rows = 8 conv2 rows).  Per group, four phases, one barrier after each (H form; cycles per group
+// and wave from the stamped build, tools/c12_diag.py, profiles/r04_*_conv12_phase_diag.txt):
+//   P1 conv1   wave (x-tile, 16-channel slice) computes the 8 new p1 rows of the group from the crop's [hi | lo] records in LDS
+//              (made IN PLACE from the staged fp32 crop, once per cell, by the threads that staged it): all nine taps of the 3x3
+//              window in one K = 32 fragment, two MFMAs per 16 pixels x 16 filters; the vertical tile pair is the pool window;
+//              bias -> ReLU -> BN -> max; rows go to a 10-slot ring in LDS (slot = row mod 10; two rows carry over).     2.5 k
+//   P2 V=B^TdB thread (tile, channel PAIR, half of the transform rows): ds_read_b64, packed-fp32 transforms, one v_cvt_pk_f16_f32 +
+//              two v_fma_mix per pair for [hi c | hi c+1] / [lo c | lo c+1], V written in the A-operand order of P3.        2.4 k
 //   P3 MFMA    wave (column group g of 3 transform-domain columns, 16-filter slice): U = G g G^T of its
-//              18 points x 32 channels stays in 144 VGPRs for the life of the workgroup; per column 6 rows x
-//              8 MFMAs, row fold s = A^T M in registers.  Output rows (2g, 2g+1) of s stay; the other two
-//              go to the partner wave (same slice, other column group) through LDS that is dead at this
-//              point (the ring's 8 consumed slots + a 16 KB area).
+//              18 points x 32 channels stays in 144 VGPRs for the life of the workgroup; per point two ds_read_b128 and three
+//              MFMAs; row fold s = A^T M in registers.  Output rows (2g, 2g+1) of s stay; the other two go to the partner wave
+//              (same slice, other column group) through LDS that is dead at this point (the ring's 8 consumed slots + a 16 KB
+//              area).  Bound by the LDS reads of V (every element is read by the four waves that share its columns): with
+//              neither MFMAs nor fold the phase still takes 1.9 k of its                                              3.1 k
 //   P4 Y=sA    column fold of the wave's two output rows over all six columns, bias -> ReLU -> BN -> 2x2
-//              max (those two rows are one pool row), store p2.
-// LDS map: V 73,728 (its first 11.5 KB double as the crop records of the next group between P3 and P2) | ring 10 x 34 x 32 x 4 =
-// 43,520 | exchange 16,384 | crop 66 x 72 x 4 = 19,008 | conv1 fragments (fp32 and bf16 forms) and epilogue constants 9,344.
+//              max (those two rows are one pool row), store p2.                                                        1.4 k
+// (+ four barriers: 1.4 k.)  LDS map: V 73,728 | ring 10 x (34 x 32 + 8) x 4 = 43,840 | exchange 16,384 | crop 67 x 72 x 4 =
+// 19,296 | conv1 fragments (both forms) and epilogue constants 9,344 | the crop's maximum 16.
 #include "common.hpp"
 
 #include <cmath>
@@ -235,31 +239,22 @@ __device__ __forceinline__ void f16x2_split6_pairs(const f32x2 (&v)[6], unsigned
 //           where the crop is staged (once per cell).  The ring holds S p1 at no cost (conv1's BN constants times S: a
 //           power of two commutes with every rounding), V = B^T d B comes out scaled, U carries the layer's S_w from the host, and
 //           the conv2 epilogue's sign factor carries 1 / (S S_w).
-//   P2      a thread splits its 36 values; the 16-byte A fragments want 8 CHANNELS of one plane, a thread owns one channel: the
-//           [hi | lo] dword goes to the neighbouring lane (channel ^ 1) by DPP and one v_perm_b32 leaves the even lane with
-//           [hi c | hi c+1] and the odd lane with [lo c | lo c+1] -- 36 ds_write_b32 as before.
+//   P2      the 16-byte A fragments want 8 CHANNELS of one plane: a thread owns a channel PAIR, so its [hi c | hi c+1] and
+//           [lo c | lo c+1] dwords are whole (one v_cvt_pk_f16_f32 + two v_fma_mix per pair; 36 ds_write_b32 per thread).
 //   V       [point][tile 16][slot 8 ^ ((tile >> 1) & 7)][16 B]: slots 0-3 = hi of channels 8 kq .., 4-7 = lo; the XOR makes every
 //           16-lane group of P3's ds_read_b128 land on 16 distinct slots, and a half wave's writes cover one tile's 128 bytes.
 //   P3      per point two ds_read_b128 and three MFMAs (hi lo, lo hi, hi hi in that order on one accumulator: small terms first).
-// C1X3: conv1 (P1) on the bf16 matrix pipe.  Its K is only 9 taps, so the three bf16 planes of the input are packed ALONG K:
-// a pixel is a 4-slot record [x1, x2, x3, x1], a K = 32 fragment is eight taps' records, and the six split products become THREE
-// MFMAs on the same A registers, one per order of magnitude: B = [w1, 0, 0, 0] per tap gives x1 w1, [w2, w1, 0, 0] gives
-// x1 w2 + x2 w1, [0, w2, w1, w3] gives x2 w2 + x3 w1 + x1 w3.  (Two MFMAs would do -- [w1, w1, w1, 0] and [w2, w2, 0, w3] -- but an
-// MFMA that sums terms 2^16 apart in ONE instruction measurably loses the small ones: p2 error 4.0e-6 of the range against
-// 2.4e-6; kept apart, the hardware's in-instruction sum only ever sees terms of one magnitude, as in the other split-bf16 kernels.)
-// A lane's fragment is two 8-byte LDS reads (the records of taps 2 kq and 2 kq + 1 of its pixel) -- no VALU.  The ninth tap
-// (2,2) is four fp32 fmas on the accumulators (lane = filter, register = pixel: the pixel's value is an LDS broadcast).
-// 48 cycles of matrix time per 16 pixels x 16 filters instead of 96, and these MFMAs leave issue slots to the pooling
-// epilogue of the SIMD's other wave.  The records of the rows a group needs are made in P4 of the previous group (the V area
-// is dead from the end of P3 to the start of P2) from the fp32 crop, which stays for the ninth tap.
-template <bool DIAG, bool C1X3, bool C2H, bool C1H = false>
+// C1H: conv1 (P1) likewise.  Its K is only 9 taps: a pixel is ONE dword record [hi | lo] and all nine taps of the 3x3 window
+// (x 2 planes) sit in one K = 32 fragment (see P1); the large products and the cross terms are two MFMAs on the same A registers
+// (one magnitude per instruction: the in-instruction adder truncates ~25 bits below its largest addend).
+template <bool DIAG, bool H>
 __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __restrict__ x, const float* __restrict__ w1frag,
                                                               const float* __restrict__ ep1, const float* __restrict__ ufrag,
                                                               const float* __restrict__ ep2, float* __restrict__ p2, long n_cells,
                                                               unsigned long long* __restrict__ diag, const unsigned int* __restrict__ w1x3,
                                                               float p1a, float p1b, float inv_sw, float inv_sw1)
 {
-    static_assert(C1X3 == C2H && C2H == C1H, "two forms: everything on fp32 MFMAs, or conv1 and conv2 as fp16 splits");
+    constexpr bool C2H = H, C1H = H;            // conv2's / conv1's contraction as a two-term fp16 split (the two always go together)
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const ring = (float*)(smem + OFF_RING);
@@ -900,8 +895,8 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
         hipError_t e;
 #define C12_ATTR(...)                                                                                                                \
     if ((e = hipFuncSetAttribute((const void*)conv12_fused_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)) != hipSuccess) return e
-        C12_ATTR(false, false, false, false); C12_ATTR(true, false, false, false);
-        C12_ATTR(false, true, true, true); C12_ATTR(true, true, true, true);
+        C12_ATTR(false, false); C12_ATTR(true, false);
+        C12_ATTR(false, true); C12_ATTR(true, true);
 #undef C12_ATTR
         int dev = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
@@ -920,11 +915,11 @@ hipError_t launch_conv12_fused(const float* x, const float* w1frag, const float*
     hipLaunchKernelGGL((conv12_fused_kernel<__VA_ARGS__>), dim3(grid), dim3(NTHR), LDS_BYTES, stream, x, w1frag, ep1, UF, ep2, p2,   \
                        (long)n_cells, dp, W1, p1a, p1b, inv_sw, ISW1)
     if (w1h2) {      // CS_PRECISION_SPLIT16: conv1 and conv2 as fp16 splits
-        if (diag) C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, true, true, true, true);
-        else C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, false, true, true, true);
+        if (diag) C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, true, true);
+        else C12_GO((const float*)ufrag_h2, w1h2, inv_sw1, false, true);
     } else {         // CS_PRECISION_FP32_EXACT
-        if (diag) C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, true, false, false, false);
-        else C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, false, false, false, false);
+        if (diag) C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, true, false);
+        else C12_GO(ufrag, (const unsigned int*)nullptr, 1.0f, false, false);
     }
 #undef C12_GO
     return hipGetLastError();

@@ -26,6 +26,11 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INS
 python bench_train.py --steps 500 --warmup 30 > "$OUT/train_bench.json" 2> "$OUT/train_bench.err"; echo "train rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_train" -- python3 bench_train.py --steps 200 --warmup 10 \
     --no-cpu-baseline > "$OUT/train_under_rocprof.json" 2> "$OUT/prof_train.err"; echo "train stats rc=$?"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_train" -- python3 tools/train_trace.py > "$OUT/train_trace.out" 2> /dev/null; echo "train trace rc=$?"
+python tools/trace_gaps.py "$(ls -t "$OUT"/trace_train/*/*_kernel_trace.csv | head -1)" 200 > "$OUT/train_step_trace.txt"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_var" -- python3 tools/train_trace.py --variant > "$OUT/train_variant_trace.out" 2> /dev/null; echo "variant trace rc=$?"
+python tools/trace_gaps.py "$(ls -t "$OUT"/trace_var/*/*_kernel_trace.csv | head -1)" 80 > "$OUT/train_variant_trace.txt"
+python bench_train.py --variant --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/train_variant_bench.json" 2> /dev/null; echo "variant train rc=$?"
 python bench_preprocess.py > "$OUT/preprocess_bench.json" 2> "$OUT/preprocess_bench.err"; echo "preprocess rc=$?"
 python tools/bench_host_path.py > "$OUT/host_path.json" 2> "$OUT/host_path.err"; echo "host path rc=$?"
 python tools/bench_variant.py > "$OUT/large_variant_bench.json" 2> "$OUT/large_variant_bench.err"; echo "variant rc=$?"
@@ -39,12 +44,15 @@ python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" 65536 > "profiles/
 python tools/pmc_sq.py "$OUT/pmc_sq1" "$OUT/pmc_sq2" > "profiles/${TAG}_sq_counters.json"
 cp "$OUT/train_bench.json" "profiles/${TAG}_train_bench.json"
 cp "$(ls -t "$OUT"/prof_train/*/*_kernel_stats.csv | head -1)" "profiles/${TAG}_train_kernel_stats.csv"
+cp "$OUT/train_step_trace.txt" "profiles/${TAG}_train_step_trace.txt"
+cp "$OUT/train_variant_trace.txt" "profiles/${TAG}_train_variant_trace.txt"
+cp "$OUT/train_variant_bench.json" "profiles/${TAG}_train_variant_bench.json"
 cp "$OUT/preprocess_bench.json" "profiles/${TAG}_preprocess_bench.json"
 cp "$OUT/host_path.json" "profiles/${TAG}_host_path.json"
 cp "$OUT/large_variant_bench.json" "profiles/${TAG}_large_variant_bench.json"
 cp "$OUT/fit_bench.json" "profiles/${TAG}_fit_bench.json"
 cp "$OUT/conv12_phase_diag.txt" "profiles/${TAG}_conv12_phase_diag.txt"
 # the profiler's raw per-dispatch CSVs are large: keep the summaries only in what travels back
-rm -rf "$OUT"/prof "$OUT"/prof_train "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
+rm -rf "$OUT"/trace_train "$OUT"/trace_var "$OUT"/prof "$OUT"/prof_train "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
 mkdir -p "$OUT/profiles" && cp profiles/${TAG}_* "$OUT/profiles/"
 echo "profiles/${TAG}_* refreshed (copies under $OUT/profiles/); add the rows to profiles/README.md"
