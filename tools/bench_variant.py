@@ -35,7 +35,7 @@ macs = 349.18e6
 # multiply-adds the matrix pipe executes: conv1 pads K = 9 to 12, the upsample-fed conv5 / conv6 run folded (4/9), the 1-filter
 # conv7 runs on the vector ALU (not counted)
 c = [128 * 128 * 9 * 1 * 32, 64 * 64 * 9 * 32 * 64, 32 * 32 * 9 * 64 * 128, 16 * 16 * 9 * 128 * 128, 32 * 32 * 9 * 128 * 64, 64 * 64 * 9 * 64 * 32]
-folded = "CS_GENERIC_NO_FOLD" not in __import__("os").environ and "CS_GENERIC_V1" not in __import__("os").environ
+folded = True
 exec_macs = c[0] * 12 / 9 + c[1] + c[2] + c[3] + (c[4] + c[5]) * (4 / 9 if folded else 1.0)
 print(json.dumps({"workload": f"{n} crops 128x128, filters {CH}, CAE forward + reconstruction MSE/MAE", "cells_per_s": n / dt,
                   "ms_per_step": dt * 1e3, "tflops_algorithmic": 2 * macs * n / dt / 1e12, "frac_fp32_mfma_peak_algorithmic": 2 * macs * n / dt / 157.3e12,

@@ -28,7 +28,7 @@ for layer, groups in ((1, 16), (2, 4)):
     items = N * groups / 512
     key = [k for k in prof if k.startswith(f"conv{layer + 1}_")][0]
     if rc != 0 or not prof[key]["launches"]:
-        print(f"conv{layer + 1}: its stand-alone Winograd kernel did not run (rc {rc}; conv1 + conv2 run fused unless CS_NO_FUSE12=1)")
+        print(f"conv{layer + 1}: its stand-alone Winograd kernel did not run (rc {rc}; conv1 + conv2 run fused unless the handle was created with CS_DEBUG_NO_FUSE12)")
         continue
     ms = prof[key]["ms"] / prof[key]["launches"]
     print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4096); "
@@ -48,7 +48,7 @@ for layer, groups in ((5, 4), (4, 1)):
     tot = sum(v)
     items = N * groups / 256
     if rc != 0 or tot == 0:
-        print(f"conv{layer + 1}: its Winograd phase kernel did not run (rc {rc}; conv5 runs on the split-bf16 kernel unless CS_NO_BF16X3=1)")
+        print(f"conv{layer + 1}: its Winograd phase kernel did not run (rc {rc}; conv5 runs on the fp16-split kernel unless precision is fp32_exact)")
         continue
     print(f"conv{layer + 1}: rc {rc}; groups per WG {items:.0f}; cycles per group per wave {tot / items:.0f} (MFMA issue alone 4608)")
     for n_, a in zip(names5, v):
