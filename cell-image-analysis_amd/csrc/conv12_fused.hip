@@ -112,8 +112,8 @@ __device__ __forceinline__ void bt6(const float d[6], float o[6])
 }
 
 // DIAG: diagnostic build (CS_C12_DIAG=1) that stamps s_memtime at the phase boundaries of every group and sums the
-// differences per wave: [0] the previous group's fold / epilogue / stores (P4's tail) + P1, [1] wait at barrier 1, [2] P2, [3] barrier 2,
-// [4] P3, [5] barrier 3, [6] P4's head (the partner's rows, the next cell's records), [7] barrier 4.
+// differences per wave: [0] P1, [1] wait at barrier 1, [2] P2, [3] barrier 2,
+// [4] P3, [5] barrier 3, [6] P4 (fold, epilogue, stores; the next cell's records), [7] barrier 4.
 // Never used for results or timing.
 __device__ __forceinline__ unsigned long long c12_stamp()
 {
@@ -698,10 +698,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
             __syncthreads();
             C12_STAMP(5)
 
-            // ================= P4: column fold of this wave's two output rows, epilogue, store.  The group's LAST barrier sits right
-            // behind the partner's rows being read (and, for the last group, behind the next cell's records): what follows -- the
-            // fold, the epilogue, the stores -- touches no LDS, so it runs into the next group's P1 without another synchronisation
-            // (the barrier used to stand at the end of P4, where the waves arrive a few hundred cycles apart).
+            // ================= P4: column fold of this wave's two output rows, epilogue, store.  The group's last barrier stands BEHIND
+            // the stores.  Right behind the partner rows' reads it would save the few hundred cycles the waves arrive apart here (-2.7 %
+            // measured), but with the fold and the stores running straight into the next group's P1 the kernel stopped being
+            // deterministic on gfx950: about one cell in 16,000 got one pooled value per filter of one wave computed as if its ReLU
+            // input were 0 (always the wave's last-but-one store, lanes 48-63); 64 idle cycles behind the stores, a wait for them, or
+            // this barrier each made it disappear, a late read of the stores' data registers was ruled out with sentinels.  The cause
+            // was not found, so the arrangement that passes tools/determinism_stress.py stays.
             {
                 const int wp = w ^ 1;
                 const int pslot = (8 * g + wp) % RING_SLOTS;
@@ -710,22 +713,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 const int co = sl * 16 + li2;
                 f32x4 e2v = *(const f32x4*)(smem + OFF_EP2 + co * 16);                // bias, bn scale, bn shift, sign
                 if constexpr (C2H) e2v[3] *= vunscale;                                // the sums carry S S_w: undone in pool_post's fma
-                if constexpr (C2H) {
-                    if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2 (THIS cell's unscale is in e2v)
-                }
-                if constexpr (C1H) {
-                    if (g == 3 && has_next) records_in_place(t2);     // the next cell's crop (this thread's own eight values, staged in P2)
-                }
-                f32x4 pa[2], pb[2], pc[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    pa[i] = *(const f32x4*)(e1 + (0 + i) * 1024);
-                    pb[i] = *(const f32x4*)(e1 + (2 + i) * 1024);
-                    pc[i] = *(const f32x4*)(e2 + i * 1024);
-                }
-                C12_STAMP(6)
-                __syncthreads();   // the exchange area inside the ring is consumed (and the records are complete) before the next P1
-                C12_STAMP(7)
                 // register r <-> tile 4 kq + r of the group (tile row kq >> 1, tile columns 4 (kq & 1) + r); output rows
                 // (2 gcol, 2 gcol + 1) of a tile are pool row gcol: one base address per lane, the rest immediates
                 float* const obase = p2 + ((((size_t)cell * 16 + 2 * (2 * g + (kq2 >> 1)) + gcol) * 16 + 8 * (kq2 & 1)) * 64 + co);
@@ -734,9 +721,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                     f32x4 y[2][4];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+                        const f32x4 pa = *(const f32x4*)(e1 + (0 + i) * 1024), pb = *(const f32x4*)(e1 + (2 + i) * 1024),
+                                    pc = *(const f32x4*)(e2 + i * 1024);
                         // this wave's columns are 0..2 (FIRST) or 3..5 of the transform domain
-                        const f32x4 s0 = FIRST ? own[0][i] : pa[i], s1 = FIRST ? own[1][i] : pb[i], s2 = FIRST ? own[2][i] : pc[i];
-                        const f32x4 s3 = FIRST ? pa[i] : own[0][i], s4 = FIRST ? pb[i] : own[1][i], s5 = FIRST ? pc[i] : own[2][i];
+                        const f32x4 s0 = FIRST ? own[0][i] : pa, s1 = FIRST ? own[1][i] : pb, s2 = FIRST ? own[2][i] : pc;
+                        const f32x4 s3 = FIRST ? pa : own[0][i], s4 = FIRST ? pb : own[1][i], s5 = FIRST ? pc : own[2][i];
                         const f32x4 p = s1 + s2, mq = s1 - s2, u = s3 + s4, v = s3 - s4;
                         y[i][0] = s0 + p + u;
                         y[i][1] = mq + 2.0f * v;
@@ -751,7 +740,16 @@ __global__ __launch_bounds__(NTHR, 2) void conv12_fused_kernel(const float* __re
                 };
                 if (gcol == 0) finish(std::true_type{});
                 else finish(std::false_type{});
+                if constexpr (C2H) {
+                    if (g == 3 && has_next) set_scale();     // the next crop's maximum is complete since the barrier after P2 (this group's sums are out)
+                }
+                if constexpr (C1H) {
+                    if (g == 3 && has_next) records_in_place(t2);     // the next cell's crop (this thread's own eight values, staged in P2)
+                }
             }
+            C12_STAMP(6)
+            __syncthreads();   // the exchange area inside the ring is consumed before the next P1 refills those slots
+            C12_STAMP(7)
         }
     }
     if constexpr (DIAG) {

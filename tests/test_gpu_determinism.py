@@ -1,0 +1,39 @@
+"""Run-to-run determinism of the screening path (-m gpu): the same library on the same crops gives the same BITS on every launch.
+The parity tests compare a few hundred cells against the oracle inside a tolerance; a result that depends on how the waves of a
+workgroup happen to interleave (a missing barrier, an instruction hazard the compiler cannot see inside inline asm) hits one value
+in tens of thousands of cells and passes them all.  Round 4 had such a fault in the fused conv1 + conv2 kernel for a few commits
+(DESIGN.md 6b): about one cell in 16,000, found only by this comparison.  tools/determinism_stress.py is the long form."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cellscreen import synth
+from cellscreen.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return a.view(f"u{a.dtype.itemsize}")
+
+
+@pytest.mark.parametrize("precision,reps", [("split16", 24), ("fp32_exact", 6)])
+def test_every_stage_is_bit_identical_from_launch_to_launch(golden_det, precision, reps):
+    import torch
+    n = 8192                                              # 32 cells per workgroup of the persistent kernels: every wave pairing occurs
+    e = Engine.from_weights(synth.random_cae(seed=42), None, H.det_from_golden(golden_det), precision=precision)
+    x = torch.empty((n, 64, 64), dtype=torch.float32, device="cuda")
+    e.synth_crops(42, 0, x)
+
+    def run():
+        out = {f"layer{l}": e.layer_output(x, l).cpu().numpy() for l in range(4)}
+        out.update({k: v.cpu().numpy() for k, v in e.screen(x).items()})
+        return out
+
+    ref = run()
+    for r in range(reps):
+        cur = run()
+        for k in ref:
+            d = _bits(cur[k]) != _bits(ref[k])
+            assert not d.any(), f"run {r}: {k} differs from the first run in {int(d.sum())} elements, first at {np.argwhere(d)[0].tolist()}"
+    e.close()

@@ -28,5 +28,5 @@ groups = N * 4 / 256
 ms = prof["conv1_conv2_fused"]["ms"] / prof["conv1_conv2_fused"]["launches"]
 print(f"conv1+conv2 fused: rc {rc}; groups per WG {groups:.0f}; cycles per group per wave {tot / groups:.0f} (16-bit MFMA issue alone: 174 x 16 = 2784 SIMD-cycles per group); "
       f"launch {ms:.3f} ms -> s_memtime rate {tot / (ms * 1e-3) / 1e9:.3f} GHz")
-for n_, a in zip(["P4 fold+store, P1 conv1", "barrier 1", "P2 transform", "barrier 2", "P3 MFMA+row fold", "barrier 3", "P4 head (partner rows)", "barrier 4"], v):
+for n_, a in zip(["P1 conv1", "barrier 1", "P2 transform", "barrier 2", "P3 MFMA+row fold", "barrier 3", "P4 fold+store", "barrier 4"], v):
     print(f"    {n_:24s} {a / groups:8.0f} cycles/group  {100 * a / tot:5.1f} %")

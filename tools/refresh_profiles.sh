@@ -36,6 +36,7 @@ python tools/bench_host_path.py > "$OUT/host_path.json" 2> "$OUT/host_path.err";
 python tools/bench_variant.py > "$OUT/large_variant_bench.json" 2> "$OUT/large_variant_bench.err"; echo "variant rc=$?"
 python tools/bench_fit.py --n 50000 > "$OUT/fit_bench.json" 2> "$OUT/fit_bench.err"; echo "fit rc=$?"
 python tools/c12_diag.py > "$OUT/conv12_phase_diag.txt" 2> /dev/null; echo "diag rc=$?"
+python tools/determinism_stress.py --reps 100 2> /dev/null | grep -v amdgpu.ids > "$OUT/determinism.txt"; echo "determinism rc=$?"
 
 cp "$OUT/bench.json" "profiles/${TAG}_bench.json"
 cp "$OUT/bench_under_rocprof.json" "profiles/${TAG}_bench_under_rocprof.json"
@@ -52,6 +53,7 @@ cp "$OUT/host_path.json" "profiles/${TAG}_host_path.json"
 cp "$OUT/large_variant_bench.json" "profiles/${TAG}_large_variant_bench.json"
 cp "$OUT/fit_bench.json" "profiles/${TAG}_fit_bench.json"
 cp "$OUT/conv12_phase_diag.txt" "profiles/${TAG}_conv12_phase_diag.txt"
+cp "$OUT/determinism.txt" "profiles/${TAG}_determinism.txt"
 # the profiler's raw per-dispatch CSVs are large: keep the summaries only in what travels back
 rm -rf "$OUT"/trace_train "$OUT"/trace_var "$OUT"/prof "$OUT"/prof_train "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
 mkdir -p "$OUT/profiles" && cp profiles/${TAG}_* "$OUT/profiles/"
