@@ -40,6 +40,20 @@ def test_reference_sequence_counterpart_matches_the_oracle():
         H.flags_agree(-last[f"{name}_score"], last[f"{name}_pred"], ref[f"{name}_dec"], ref[f"{name}_pred"], tol, name)
 
 
+def test_oracle_port_baseline_is_timed_inside_the_hosts_cpu_share():
+    """`cpu_baseline` itself (kind "port"): the OpenMP oracle at the best thread count of a sweep that stays inside the affinity
+    mask and the cgroup quota; its results double as the bench line's live parity sample."""
+    import bench
+    w = synth.random_cae(seed=42)
+    det = H.det_from_golden(np.load(os.path.join(H.ROOT, "tests", "golden", "golden_detector.npz")))
+    port, res, x = bench.cpu_port(w, det, 42, 48)
+    assert port["kind"] == "port" and port["unit"] == "cells/s" and port["value"] > 0 and len(x) == 48 == len(res["mse"])
+    sw = port["cells_per_s_by_threads"]
+    assert str(port["cores"]) in sw and sw[str(port["cores"])] == max(sw.values())
+    assert 1 <= port["cores"] <= port["host_cpus_visible"]
+    assert np.array_equal(x, oracle.synth_crops(42, 0, 48))
+
+
 def test_source_hash_names_the_kernel_sources(tmp_path):
     """profiles/*_pmc_traffic.json are accepted by bench.py only when they carry this tree's hash."""
     sys.path.insert(0, os.path.join(H.ROOT, "cell-image-analysis_amd"))

@@ -30,6 +30,7 @@ def test_committed_bench_line_has_the_contract_keys():
     c = line["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == "cells/s"
 
 
 def test_committed_bench_line_is_self_consistent():
