@@ -528,7 +528,17 @@ struct F67H {
     static constexpr int STRIP = 6 * ROWB;                     // 31,104 B
     static constexpr int TW = F67T::TW;
     static constexpr int T_BYTES = F67T::T_BYTES;
-    static constexpr int OFF_MAX = STRIP + F67::A6_BYTES + T_BYTES + F67::W_BYTES;   // two words: the strip maxima (alternating)
+    // a6 block, W_eff rows: pitches of 40 floats; a pixel's channels 0-15 / 16-31 swap places when bit 3 of its column is set.  With
+    // these every LDS access of the T stretch is conflict-free under the bank rules of gfx950 (tools/lds_bank_model.py; the previous
+    // layout -- 36 / 36, no swap -- cost 2,816 extra LDS cycles per cell, exactly SQ_LDS_BANK_CONFLICT / cells of profiles/r04_b):
+    //   a6 block   ds_write_b32, 32-lane groups over 32 banks: lanes (filter li, pixel 8 kq + ..): kq = 0 / 1 on opposite halves;
+    //   T operand  ds_read_b128 of lane (pixel 4 (li & 3) + (li >> 2), channels 4 kq .. +3 | 16 + 4 kq .. +3);
+    //   W_eff      ds_read_b128 of lane (row li, the same channels).
+    static constexpr int PA = 40;
+    static constexpr int A6_BYTES = 8 * 32 * PA * 4;           // 40,960 B
+    static constexpr int WP = 40;
+    static constexpr int W_BYTES = 16 * WP * 4;
+    static constexpr int OFF_MAX = STRIP + A6_BYTES + T_BYTES + W_BYTES;   // two words: the strip maxima (alternating)
     static constexpr int LDS = OFF_MAX + 16;
     static_assert(LDS <= 160 * 1024 && STRIP % 16 == 0, "LDS budget");
 };
@@ -598,8 +608,8 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
     unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* a6s = (float*)(smem + F67H::STRIP);
-    float* tb = (float*)(smem + F67H::STRIP + F67::A6_BYTES);
-    float* wl = (float*)(smem + F67H::STRIP + F67::A6_BYTES + F67H::T_BYTES);
+    float* tb = (float*)(smem + F67H::STRIP + F67H::A6_BYTES);
+    float* wl = (float*)(smem + F67H::STRIP + F67H::A6_BYTES + F67H::T_BYTES);
     unsigned int* mxw = (unsigned int*)(smem + F67H::OFF_MAX);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -615,6 +625,7 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
 #pragma unroll
             for (int p = 0; p < 2; ++p) B[t][k][p] = wfrag[(((wave * 4 + t) * 2 + k) * 2 + p) * 64 + lane];
     const int co = wsl * 16 + li;
+    const int cosw = co ^ ((kq & 1) << 4);                         // where filter co of this lane's a6 pixels lives (F67H)
     const float bias = ep[co], bns = ep[C::COUT + co], bnt = ep[2 * C::COUT + co];
     const float b7 = b7p[0];
 
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
     auto cell_ptr = [&](long cell) { return in + (size_t)cell * C::HS * C::WS * C::CIN; };
     for (int i = tid; i < F67H::LDS / 16; i += C::THREADS) ((f32x4*)smem)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
-    wl[(tid >> 5) * 36 + (tid & 31)] = weff[tid];                  // [n][c], 512 floats, padded rows
+    wl[(tid >> 5) * F67H::WP + (tid & 31)] = weff[tid];            // [n][c], 512 floats, padded rows
     float unscale;                                                 // 1 / (S_a S_w) of the strip the MFMAs read
     {
         f32x4 stg[C::NLD];
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(fmaf(ah[t][r] + al[t][r], unscale, bias), 0.0f);
-                    a6s[((2 * t + pa) * 32 + 2 * (4 * kq + r) + pb) * F67::PA + co] = fmaf(v, bns, bnt);
+                    a6s[((2 * t + pa) * 32 + 2 * (4 * kq + r) + pb) * F67H::PA + cosw] = fmaf(v, bns, bnt);     // column 8 kq + 2 r + pb: bit 3 = kq & 1
                 }
             // the next strip's values are here by now (loaded at the top of the group): its max|.| into this strip's word
             if (has_next) {
@@ -734,31 +745,38 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
             }
             __syncthreads();
             if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[2] += t - dt; dt = t; }
-            // ---- T = a6 W_eff^T for local row `wave`, 16 pixels per MFMA chain; K order: channel 8 kq + s
-            float wc[8];                                                                 // W_eff[n = li][c = 8 kq + s]
-            *(f32x4*)&wc[0] = *(const f32x4*)(wl + li * 36 + kq * 8);
-            *(f32x4*)&wc[4] = *(const f32x4*)(wl + li * 36 + kq * 8 + 4);
+            // ---- T^T = W_eff a6^T for local row `wave`: the 16 transform rows n are the MFMA's rows, 16 pixels its columns, two chains
+            // (pixels x and 16 + x).  K order: step s of lane kq is channel 4 kq + (s & 3) + 16 (s >> 2).  D then has row 4 kq + r in
+            // register r of lane (pixel, kq): a ds_write_b32 of one r puts 16 neighbouring pixels of one T row on neighbouring floats.
+            // T ring rows: the four n-blocks {e = 1 | 0} x {column phase px = 0 | 1} sit at block rows {0, 1, 3, 2}, and the rows of the
+            // px = 1 blocks are stored one float to the left (their reader never wants the left halo): lanes kq = 0, 1 write
+            // blocks (0, 3), lanes 2, 3 blocks (1, 2) -- 48 and 16 floats apart mod 32 -- and the gather's even / odd lanes read
+            // blocks 16 floats apart: both conflict-free (with [n][x] rows in natural order one of the two was always 2-way).
             {
-                // A row i of the contraction is pixel 4 (i & 3) + (i >> 2) of the 16: D then has pixel 4 r + kq in register r of lane
-                // (n = li, kq), and a ds_write_b32 of one r puts kq = 0 / 1 on neighbouring floats -- with pixel 4 kq + r the lanes
-                // (li, kq), (li - 1, kq + 1), (li + 8, kq), (li + 7, kq + 1) met on one bank (4-way: 3,800 conflict cycles per cell)
-                const float* ap = a6s + ((wave * 32 + 4 * (li & 3) + (li >> 2)) * F67::PA + kq * 8);
-                const f32x4 a00 = *(const f32x4*)ap, a01 = *(const f32x4*)(ap + 4);
-                const f32x4 a10 = *(const f32x4*)(ap + 16 * F67::PA), a11 = *(const f32x4*)(ap + 16 * F67::PA + 4);
+                const int wrow = 4 * ((li >> 3) | (((li >> 2) & 1) << 1)) + (li & 3);       // A row i = li stands for n = 4 blk(i >> 2) + (i & 3), blk = (0, 2, 1, 3)
+                float wc[8];                                                                // W_eff[n][c = 4 kq + (s & 3) + 16 (s >> 2)]
+                *(f32x4*)&wc[0] = *(const f32x4*)(wl + wrow * F67H::WP + 4 * kq);
+                *(f32x4*)&wc[4] = *(const f32x4*)(wl + wrow * F67H::WP + 4 * kq + 16);
+                const int pix = 4 * (li & 3) + (li >> 2), sw = ((li >> 1) & 1) << 4;        // bit 3 of pix (and of 16 + pix) is bit 1 of li
+                const float* ap = a6s + (wave * 32 + pix) * F67H::PA + 4 * kq;
+                const f32x4 a00 = *(const f32x4*)(ap + sw), a01 = *(const f32x4*)(ap + (sw ^ 16));
+                const f32x4 a10 = *(const f32x4*)(ap + 16 * F67H::PA + sw), a11 = *(const f32x4*)(ap + 16 * F67H::PA + (sw ^ 16));
                 f32x4 t0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;                     // two independent chains, interleaved
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a00[s], wc[s], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[s], wc[s], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], a00[s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], a10[s], t1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a01[s], wc[4 + s], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11[s], wc[4 + s], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[4 + s], a01[s], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[4 + s], a11[s], t1, 0, 0, 0);
                 }
-                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + li) * F67H::TW + kq + 1;
+                // D rows of lane kq: n = 4 blk(kq) + r, n-block blk(kq) = (e, px) blocks (B0, B2, B1, B3) -> ring block rows (0, 3, 1, 2)
+                const int rblk = kq == 0 ? 0 : (kq == 1 ? 3 : (kq == 2 ? 1 : 2));
+                float* tw = tb + ((((8 * grp + wave) & (F67::TSLOTS - 1)) * 16) + 4 * rblk) * F67H::TW + pix + 1 - (kq >> 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { tw[4 * r] = t0[r]; tw[16 + 4 * r] = t1[r]; }
+                for (int r = 0; r < 4; ++r) { tw[r * F67H::TW] = t0[r]; tw[r * F67H::TW + 16] = t1[r]; }
             }
             if (has_next) {      // every wave is past the first barrier: nobody reads the current strip any more, and the word holds the maximum
                 float S, invS;
@@ -771,13 +789,15 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
             if (tid == 0) *mword = 0;            // read by everyone before the barrier above; its next atomics come two groups later
             if constexpr (DIAG) { const unsigned long long t = wu_stamp(); dg[3] += t - dt; dt = t; }
             // ---- gather: new a6 row y finishes output rows 2y - 1 (phase a = 1 of row y - 1) and 2y (a = 0)
-            const int px = lane & 1, xh = (lane >> 1) + px;                              // halo column of rx = 0
+            // n-block (e, px) sits at ring block row {0, 1, 3, 2}[(1 - e) 2 + px]; the px = 1 blocks are stored one float to the left, so
+            // the halo column of rx = 0 is float lane >> 1 in both
+            const int px = lane & 1, xh = lane >> 1;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = wave + 8 * h;                                              // wave-uniform
                 const int y = 8 * grp + (k >> 1), e = k & 1;
                 if (2 * y - 1 + e < 0) continue;
-                const int nb = ((1 - e) * 2 + px) * 4;
+                const int nb = (e ? px : 3 - px) * 4;
                 const float* ra = tb + ((((y - 1) & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
                 const float* rb = tb + (((y & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
                 float ta0 = ra[0], ta1 = ra[F67H::TW + 1];
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(WUL6::THREADS, 2) void conv67_h2_kernel(
                 s1 += fabsf(d);
             }
             if (grp == C::NGRP - 1 && wave == 0) {                                      // output row 63: a6 row 31 and the padding
-                const int nb = (2 + px) * 4;
+                const int nb = (3 - px) * 4;                                             // n-blocks (e = 0, px)
                 const float* ra = tb + (((31 & (F67::TSLOTS - 1)) * 16) + nb) * F67H::TW + xh;
                 const float v = (ra[0] + ra[F67H::TW + 1]) + b7;
                 const float rr = f67_sigmoid(v);
