@@ -37,3 +37,23 @@ def test_every_stage_is_bit_identical_from_launch_to_launch(golden_det, precisio
             d = _bits(cur[k]) != _bits(ref[k])
             assert not d.any(), f"run {r}: {k} differs from the first run in {int(d.sum())} elements, first at {np.argwhere(d)[0].tolist()}"
     e.close()
+
+
+def test_generic_shape_path_is_bit_identical_from_launch_to_launch():
+    """The run-time-shaped kernels (128x128 crops, filters 32-64-128 | 128-64-32-1: BASELINE.json configs[4]) under the same check."""
+    import torch
+    hw, ch = (128, 128), (32, 64, 128, 128, 64, 32, 1)
+    e = Engine.from_weights(synth.random_cae(seed=5, hw=hw, channels=ch, n_enc=3))
+    x = torch.rand((1024, *hw), dtype=torch.float32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+
+    def run():
+        rec, mse, mae = e.reconstruct(x, want_recon=True)
+        return {"recon": rec.cpu().numpy(), "mse": mse.cpu().numpy(), "mae": mae.cpu().numpy(), "features": e.encode(x).cpu().numpy()}
+
+    ref = run()
+    for r in range(8):
+        cur = run()
+        for k in ref:
+            d = _bits(cur[k]) != _bits(ref[k])
+            assert not d.any(), f"run {r}: {k} differs from the first run in {int(d.sum())} elements, first at {np.argwhere(d)[0].tolist()}"
+    e.close()
