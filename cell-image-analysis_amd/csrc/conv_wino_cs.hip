@@ -315,16 +315,35 @@ __device__ __forceinline__ void w3h_scale(unsigned int mbits, float& S, float& i
     S = __builtin_bit_cast(float, (unsigned int)(268 - E) << 23);
     invS = __builtin_bit_cast(float, (unsigned int)(E - 14) << 23);
 }
+// Eight scaled values -> their hi and lo fragments as ONE block of 12 instructions (v_cvt_pk_f16_f32 per pair, then the residuals as
+// v_fma_mix{lo,hi}_f16: exact in fp32, one rounding); the convert / convert back / subtract / convert form compiled to ~ 20 and the
+// kernel ran 2.3 % slower (24.7 vs 24.1 ms per 1 M cells; per-VALUE asm blocks had measured slower in round 3: common.hpp).  -0
+// residuals come out +0.  The results feed MFMAs directly, which the hazard recogniser cannot see through the asm: the block ends with the two wait
+// states a VALU write -> MFMA read needs.
 __device__ __forceinline__ void w3h_split8(const f32x4& lo4, const f32x4& hi4, float S, f16x8& ah, f16x8& al)
 {
     const f32x4 a = lo4 * S, b = hi4 * S;
-    const f16x4 ha = __builtin_convertvector(a, f16x4), hb = __builtin_convertvector(b, f16x4);
-    const f32x4 ra = a - __builtin_convertvector(ha, f32x4), rb = b - __builtin_convertvector(hb, f32x4);     // exact in fp32
-    const f16x4 la = __builtin_convertvector(ra, f16x4), lb = __builtin_convertvector(rb, f16x4);
-    ah = f16x8{ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
-    al = f16x8{la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+    const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    unsigned int h0, h1, h2, h3, l0, l1, l2, l3;
+    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
+        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
+        "v_fma_mixlo_f16 %4, %8, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %5, %10, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %6, %12, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %14, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %4, %9, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %5, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %13, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %15, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    ah = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+    al = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
 }
-
 __global__ __launch_bounds__(256, 2) void conv3_wino_h2_kernel(const float* __restrict__ in, const f16x8* __restrict__ ufrag,
                                                               const float* __restrict__ ep /* [3][32] */, float* __restrict__ out,
                                                               long n_cells, float inv_sw)
