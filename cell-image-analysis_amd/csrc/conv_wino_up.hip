@@ -495,9 +495,8 @@ __global__ __launch_bounds__(WUL6::THREADS, 1) void conv67_fused_kernel(
 //   wave = (phase, 16-filter half): B = 4 taps x 2 channel blocks x 2 planes x 4 VGPRs = 64 registers; a tile is one stored
 //          row of the group (16 pixels), its A fragment of one (tap, block) two ds_read_b128 at immediate offsets;
 //   everything after the a6 block (T = a6 W_eff^T on fp32 MFMAs, the T ring, gather, sigmoid, error sums) is the code above.
-// T ring, n-major: [ring row 16][n 16][x 34 -> 36].  The gather's 32 lanes of a ds_read_b32 are 16 columns x 2 column phases;
-// with the (x, n) order of the fp32 kernel a phase step is 64 B + 16 B and the 32 lanes fall on 4 banks (8-way); here a
-// phase step is 4 rows + 1 float = 145 floats = 17 banks: 31 distinct banks
+// T ring, n-major: [ring row 16][n-block row 4][n in block 4][x 34 -> 36]; which n-block sits where, the one-float shift of the column-phase-1
+// blocks and the pitches that keep every access of this stretch off shared banks are described at F67H and where T is written.
 struct F67T {
     static constexpr int TW = 36;
     static constexpr int T_BYTES = F67::TSLOTS * 16 * TW * 4;  // 36,864 B
