@@ -305,24 +305,21 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
                                                            float* __restrict__ sums /*[2][C] means*/,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    // workgroup b owns the CB = C / gridDim.x channels from b CB on: NG = 256 / CB threads per channel each sum a contiguous range of the
-    // partials in order, then the NG range sums in order (fixed for a given launch shape: deterministic).  One workgroup for all
-    // channels ran G C / 256 dependent loads per thread: 12 us per layer at C = 128.
     __shared__ double s0[256], s1[256];
-    const int CB = C / gridDim.x, tid = threadIdx.x, cl = tid % CB, c = blockIdx.x * CB + cl, grp = tid / CB, NG = 256 / CB;
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C, NG = 256 / C;
     const int g0 = (G * grp) / NG, g1 = (G * (grp + 1)) / NG;
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll 4
     for (int g = g0; g < g1; ++g) { t0 += part[(size_t)g * 2 * C + c]; t1 += part[(size_t)g * 2 * C + C + c]; }
     s0[tid] = t0; s1[tid] = t1;
     __syncthreads();
-    if (tid < CB) {
+    if (tid < C) {
         t0 = 0.0; t1 = 0.0;
-        for (int k = 0; k < NG; ++k) { t0 += s0[k * CB + tid]; t1 += s1[k * CB + tid]; }
-        sums[c] = (float)(t0 / nred);
-        sums[C + c] = (float)(t1 / nred);
-        dbeta[c] = (float)t0;
-        dgamma[c] = (float)t1;
+        for (int k = 0; k < NG; ++k) { t0 += s0[k * C + tid]; t1 += s1[k * C + tid]; }
+        sums[tid] = (float)(t0 / nred);
+        sums[C + tid] = (float)(t1 / nred);
+        dbeta[tid] = (float)t0;
+        dgamma[tid] = (float)t1;
     }
 }
 
@@ -845,8 +842,7 @@ hipError_t launch_bn_bwd_reduce(const float* da, const float* r, const float* st
 hipError_t launch_bn_bwd_final(const float* part, int G, int C, double nred, float* sums, float* dgamma, float* dbeta,
                                hipStream_t s)
 {
-    const unsigned blocks = (C >= 64 && C % 32 == 0) ? (unsigned)(C / 32) : 1u;      // 32 channels per workgroup where C allows it
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(blocks), dim3(256), 0, s, part, G, C, nred, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, s, part, G, C, nred, sums, dgamma, dbeta);
     return hipGetLastError();
 }
 
